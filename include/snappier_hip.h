@@ -1,0 +1,158 @@
+/*
+ * snappier_hip.h -- C-ABI of libsnappier_hip.so, the MI355X (gfx950) Snappy block codec.
+ *
+ * This is the drop-in boundary.  Snappier itself has no FFI seam (it is pure C#,
+ * Snappier/Snappier.csproj:19-22); the entry points below are what a C# shim would P/Invoke to replace the
+ * bodies of the reference methods cited on each declaration.  Plain pointers and sizes only; no exceptions
+ * cross the boundary -- every call returns an snp_status that maps 1:1 onto the reference's outcome
+ * (Snappier/Internal/ThrowHelper.cs:8-36).
+ *
+ * Memory spaces: entry points suffixed _batch / _device take DEVICE pointers (hipMalloc'd memory, e.g. a torch
+ * tensor's data_ptr()) and enqueue on the context's stream; all other entry points take HOST pointers, stage
+ * through context-owned HBM scratch, and block until the result is in the caller's buffer (the reference's
+ * Span API is synchronous, Snappy.cs:37,153).  There is no CPU fallback: without a HIP device
+ * snp_ctx_create fails with SNP_ERR_DEVICE.
+ */
+#ifndef SNAPPIER_HIP_H
+#define SNAPPIER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (reference outcome each one stands for) --------------------------------------------- */
+typedef enum snp_status {
+    SNP_OK = 0,
+    /* Try* returned false / ArgumentException("Output buffer is too small.")  ThrowHelper.cs:18-19 */
+    SNP_ERR_OUTPUT_TOO_SMALL = 1,
+    /* InvalidDataException("Invalid copy offset")  SnappyDecompressor.cs:598-601 */
+    SNP_ERR_BAD_OFFSET = 2,
+    /* InvalidDataException("Data too long")  SnappyDecompressor.cs:570-573,603-606 */
+    SNP_ERR_TOO_LONG = 3,
+    /* InvalidDataException("Incomplete Snappy block.")  Snappy.cs:178-181,229-232 */
+    SNP_ERR_INCOMPLETE = 4,
+    /* InvalidDataException("Invalid stream length")  VarIntEncoding.Read.cs:18-21 */
+    SNP_ERR_BAD_LENGTH = 5,
+    /* InvalidDataException("Chunk CRC mismatch.")  SnappyStreamDecompressor.cs:127-131,170-174 */
+    SNP_ERR_CRC_MISMATCH = 6,
+    /* InvalidDataException("Unknown chunk type ..")  SnappyStreamDecompressor.cs:182-185 */
+    SNP_ERR_CHUNK_TYPE = 7,
+    /* InvalidOperationException("Input and output spans must not overlap.")  SnappyCompressor.cs:27-30 */
+    SNP_ERR_OVERLAP = 8,
+    /* ArgumentNullException / ArgumentException on the managed side */
+    SNP_ERR_BAD_ARG = 9,
+    /* no usable HIP device, or a HIP runtime call failed (no reference analogue; surfaces as InvalidOperation) */
+    SNP_ERR_DEVICE = 10,
+    /* framed stream ends inside a chunk header or chunk body (reference: the Stream simply returns 0 bytes) */
+    SNP_ERR_TRUNCATED_STREAM = 11
+} snp_status;
+
+/* Which TableEntry hash the compressor reproduces (Snappier/Internal/HashTable.cs:91-126). */
+typedef enum snp_hash_variant {
+    SNP_HASH_CRC32C = 0, /* x64 SSE4.2 / ARM CRC path, .NET 8+ (HashTable.cs:109-117) -- Snappier's default on the GPU box host */
+    SNP_HASH_MUL = 1     /* (0x1e35a7bd * bytes) >> 17 fallback (HashTable.cs:121-122) -- what the golden .snappy fixtures were made with */
+} snp_hash_variant;
+
+enum {
+    SNP_BLOCK_SIZE = 65536,               /* Constants.cs:25-26 */
+    SNP_MAX_BLOCK_COMPRESSED = 76491,     /* Helpers.cs:49  (32 + n + n/6 + 1 at n = 65536) */
+    SNP_VARINT_MAX = 5,                   /* VarIntEncoding.MaxLength */
+    SNP_STREAM_HEADER_LEN = 10,           /* SnappyStreamCompressor.cs:18-21 */
+    SNP_CHUNK_HEADER_LEN = 8              /* SnappyStreamCompressor.cs:199 */
+};
+
+typedef struct snp_ctx snp_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+
+/* One context = one HIP device + one stream + reusable HBM scratch.  Snappy.* is re-entrant because it news up
+ * a compressor per call (Snappy.cs:64,174,225); the equivalent here is one ctx per calling thread.
+ * stream == NULL: the context creates and owns a stream; otherwise it enqueues on the given hipStream_t. */
+snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** out_ctx);
+void snp_ctx_destroy(snp_ctx* ctx);
+/* Last HIP error string seen by this context ("" if none); pointer valid until the next call on ctx. */
+const char* snp_ctx_last_error(const snp_ctx* ctx);
+/* Block until everything enqueued on the context's stream is done (for the *_batch entry points). */
+snp_status snp_ctx_synchronize(snp_ctx* ctx);
+const char* snp_status_string(int status);
+const char* snp_version(void);
+
+/* ---- host-only arithmetic (no device needed) ----------------------------------------------------------- */
+
+/* Snappy.GetMaxCompressedLength  Snappy.cs:20-24  (= Helpers.MaxCompressedLength + 5).  Returns -1 if n < 0 or the result overflows int32. */
+int64_t snp_max_compressed_length(int64_t n);
+/* Helpers.MaxCompressedLength  Helpers.cs:17-46 (no varint padding). */
+int64_t snp_max_fragment_compressed_length(int64_t n);
+/* Snappy.GetUncompressedLength  Snappy.cs:136-137 -> VarIntEncoding.Read  VarIntEncoding.Read.cs:16-79. */
+snp_status snp_get_uncompressed_length(const uint8_t* in, size_t n, uint32_t* out_len, uint32_t* out_header_bytes);
+
+/* ---- single-buffer, host pointers ---------------------------------------------------------------------- */
+
+/* Snappy.TryCompress  Snappy.cs:55-67 -> SnappyCompressor.TryCompress  SnappyCompressor.cs:24-83.
+ * Any input length < 2^32: varint preamble + one compressed fragment per 65536 input bytes; fragments are
+ * compressed concurrently (one wavefront each) and concatenated on the device.
+ * SNP_ERR_OUTPUT_TOO_SMALL (written = 0) when cap cannot hold the result; SNP_ERR_OVERLAP when in/out overlap. */
+snp_status snp_try_compress(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written);
+
+/* Snappy.TryDecompress / Snappy.DecompressToMemory  Snappy.cs:172-186,223-235 -> SnappyDecompressor.Decompress
+ * SnappyDecompressor.cs:43-92,184-347.  One whole Snappy block of any declared length. */
+snp_status snp_try_decompress(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written);
+
+/* Crc32CAlgorithm.Compute + ApplyMask  Crc32CAlgorithm.cs:41-49,156-158. masked != 0 applies the framing mask. */
+snp_status snp_crc32c(snp_ctx* ctx, const uint8_t* in, size_t n, int masked, uint32_t* out_crc);
+
+/* SnappyStreamCompressor.Write + Flush over one whole buffer  SnappyStreamCompressor.cs:40-55,82-97,194-261:
+ * stream identifier + one chunk per 65536 input bytes (type 0x00 if the compressed body is smaller than the raw
+ * chunk, else type 0x01), each with the masked CRC-32C of its raw bytes. */
+int64_t snp_frame_max_encoded_length(int64_t n);
+snp_status snp_frame_encode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written);
+
+/* SnappyStreamDecompressor.Decompress over one whole framed stream  SnappyStreamDecompressor.cs:38-208:
+ * chunk types 0x00/0x01 are decoded and CRC-checked, 0x80..0xff skipped, 0x02..0x7f rejected.
+ * snp_frame_decoded_length scans chunk headers on the host and returns the total decoded size. */
+snp_status snp_frame_decoded_length(const uint8_t* in, size_t n, uint64_t* out_len);
+snp_status snp_frame_decode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written);
+
+/* ---- batch, device pointers (the hot path; asynchronous on the context's stream) ------------------------ */
+
+/* nblocks independent inputs, each <= 65536 bytes (one fragment, SnappyCompressor.cs:40-80 loop body):
+ * block b reads in[in_off[b] .. +in_len[b]) and writes  varint(in_len[b]) || CompressFragment  at
+ * out[out_off[b] ..), which must have room for snp_max_compressed_length(in_len[b]) bytes.
+ * out_len[b] = bytes written, status[b] = SNP_OK | SNP_ERR_BAD_ARG (in_len[b] > 65536).
+ * One wavefront per block; hash table in LDS.  All arrays are device memory. */
+snp_status snp_compress_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                              uint32_t nblocks, uint8_t* out, const uint64_t* out_off, uint32_t* out_len,
+                              int32_t* status);
+
+/* nblocks independent Snappy blocks: block b reads in[in_off[b] .. +in_len[b]) (varint preamble + tags) and writes
+ * at most out_cap[b] bytes at out[out_off[b] ..).  out_len[b] = declared/decoded length, status[b] per block.
+ * SnappyDecompressor.cs:184-347 semantics; one wavefront per block. */
+snp_status snp_decompress_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                                uint32_t nblocks, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
+                                uint32_t* out_len, int32_t* status);
+
+/* CRC-32C (optionally masked) of nblocks independent byte ranges; table-free, wave-parallel. */
+snp_status snp_crc32c_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                            uint32_t nblocks, int masked, uint32_t* out_crc);
+
+/* Device-resident framing (config 4): raw stream d_in[0..n) -> framed stream in d_out (capacity cap, device),
+ * *d_written (device u64) = encoded size.  d_work must hold snp_frame_encode_workspace(n) bytes. */
+uint64_t snp_frame_encode_workspace(uint64_t n);
+snp_status snp_frame_encode_device(snp_ctx* ctx, const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap,
+                                   uint64_t* d_written, void* d_work);
+/* Device-resident decode of a framed stream whose chunk table the caller already has on the device:
+ * chunk c has type chunk_type[c] (0 or 1), body d_in[body_off[c] .. +body_len[c]) (after the 4 CRC bytes),
+ * expected masked CRC chunk_crc[c], and decodes to d_out[out_off[c] .. +out_cap[c]).  status[c] per chunk. */
+snp_status snp_frame_decode_chunks_device(snp_ctx* ctx, const uint8_t* d_in, const uint8_t* chunk_type,
+                                          const uint64_t* body_off, const uint32_t* body_len,
+                                          const uint32_t* chunk_crc, uint32_t nchunks, uint8_t* d_out,
+                                          const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
+                                          int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNAPPIER_HIP_H */
