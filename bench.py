@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[1] -- 10 GiB of 64 KiB html-like blocks per GPU (163 840 blocks:
+the html fixture tiled at a per-block offset + ~1 % byte mutations, seed 0x5EED0001; weak scaling, rank r owns
+blocks [r*163840, (r+1)*163840)).  One STEP = one pass of the hot path over the batch: block-compress every block
+(snp_compress_batch), block-decompress every block back (snp_decompress_batch), then the final directory gather
+(all_gather of per-block lengths + status over RCCL when N > 1).  Inputs are resident in HBM before the timed region.
+
+value = uncompressed bytes that made the whole round trip, all GPUs, per second of wall time (max over ranks).
+Both directions are also reported separately from HIP-event kernel times, each with its roofline fraction:
+algorithmic bytes per launch = sum over blocks of (U_b + C_b)    /  average launch duration, against
+the 8 TB/s HBM3E peak.  cpu_baseline = the C oracle (oracle/snappy_oracle.c, a port of the same algorithm) timed on
+this host's cores over a bounded sample of the same blocks.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BLOCK = 65536
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(raw_sample: np.ndarray, variant: int):
+    """Oracle ("port") on the host cores over a bounded sample; returns the cpu_baseline object."""
+    import oracle as O
+    nb = raw_sample.size // BLOCK
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    in_off = (np.arange(nb, dtype=np.uint64) * np.uint64(BLOCK)).astype(np.uint64)
+    in_len = np.full(nb, BLOCK, dtype=np.uint32)
+    O.compress_batch(raw_sample[: 64 * BLOCK], in_off[:64], in_len[:64], variant, threads)      # warm up / page in
+    reps, t_c, t_d = 0, 0.0, 0.0
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        out, out_off, out_len, status = O.compress_batch(raw_sample, in_off, in_len, variant, threads)
+        t1 = time.perf_counter()
+        dec, dlen, dst = O.decompress_batch(out, out_off, out_len, in_off, in_len, raw_sample.size, threads)
+        t2 = time.perf_counter()
+        t_c += t1 - t0
+        t_d += t2 - t1
+        reps += 1
+        assert (status == 0).all() and (dst == 0).all()
+        if reps >= 3 or (time.perf_counter() - t_start) > 20.0:
+            break
+    assert dec.tobytes() == raw_sample.tobytes()
+    u = float(nb) * BLOCK * reps
+    return {
+        "value": round(u / (t_c + t_d) / 1e9, 3), "unit": "GB/s uncompressed, compress+decompress round trip",
+        "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+        "compress_GBps": round(u / t_c / 1e9, 3), "decompress_GBps": round(u / t_d / 1e9, 3),
+        "sample": f"{nb} of the same html-like 64 KiB blocks x {reps} passes, {threads} threads (blocks striped), "
+                  f"C oracle built -O2 -msse4.2 (hash = SSE4.2 crc32, as Snappier on x64/.NET 8+)",
+        "note": "Snappier's C# path is not runnable on this host (no .NET runtime); the oracle is a C port of the same algorithm",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=163840, help="64 KiB blocks per GPU (163840 = 10 GiB)")
+    ap.add_argument("--hash", choices=["crc32c", "mul"], default="crc32c")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-blocks", type=int, default=16384)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the codec has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
+
+    import snappier_amd as S
+    from snappier_amd import batch as SB, datagen as SD, sharding
+
+    variant = S.HASH_CRC32C if args.hash == "crc32c" else S.HASH_MUL
+    nb = args.blocks
+    free, _tot = torch.cuda.mem_get_info()
+    need = nb * (2 * BLOCK + 76512) + (3 << 30)
+    if free < need:
+        nb = int((free - (3 << 30)) // (2 * BLOCK + 76512)) // 1024 * 1024
+        print(f"[bench] only {free >> 30} GiB free: reduced to {nb} blocks per GPU", file=sys.stderr)
+
+    with open(os.path.join(ROOT, "tests", "golden", "testdata", "html"), "rb") as f:
+        html = f.read()
+    cd = SB.BlockCodec(local_rank, variant)
+    raw = SD.html_like_blocks(html, rank * nb, nb, dev)
+    in_off, in_len = cd.uniform_layout(nb)
+    comp = torch.empty(nb * cd.comp_stride, dtype=torch.uint8, device=dev)
+    comp_off = torch.arange(nb, dtype=torch.int64, device=dev) * cd.comp_stride
+    back = torch.empty_like(raw)
+    torch.cuda.synchronize()
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731  (recorded on the stream the kernels run on)
+    t_comp, t_dec = [], []
+
+    def step(record: bool):
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        _o, _oo, out_len, status = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
+        e1.record()
+        dlen, dst = cd.decompress(comp, comp_off, out_len, back, in_off, in_len)
+        e2.record()
+        if world > 1:                                       # the one exchange step: (length, status) directory
+            sharding.gather_directory(out_len, status, nb * world)
+        if record:
+            t_comp.append((e0, e1))
+            t_dec.append((e1, e2))
+        return out_len, status, dlen, dst
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_len, status, dlen, dst = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- verification (outside the timed region): every status OK, decode(encode(x)) == x -----------------------
+    ok = int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and bool((dlen == BLOCK).all()) and torch.equal(back, raw)
+    if not ok:
+        sys.exit("[bench] round trip is NOT bit-exact -- number invalid")
+    c_bytes = float(out_len.to(torch.int64).sum().item())
+    u_bytes = float(nb) * BLOCK
+    ms_c = float(np.mean([a.elapsed_time(b) for a, b in t_comp]))
+    ms_d = float(np.mean([a.elapsed_time(b) for a, b in t_dec]))
+
+    if rank == 0:
+        total_u = u_bytes * world
+        ms_per_step = elapsed / args.steps * 1e3
+        alg = u_bytes + c_bytes                                     # U + C for compress, C + U for decompress
+        def roof(ms, kernel):
+            a = alg / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": round(a, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBPS, 5), "traffic": None, "avg_launch_ms": round(ms, 4),
+                    "algorithmic_bytes_per_launch": int(alg),
+                    "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}
+        r_c, r_d = roof(ms_c, "k_compress"), roof(ms_d, "k_decompress")
+        line = {
+            "metric": "uncompressed GB/s block compress+decompress, 64 KiB blocks",
+            "value": round(total_u / (elapsed / args.steps) / 1e9, 3),
+            "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: 10 GiB of 64 KiB html-like blocks per GPU, one block per wavefront, "
+                                   "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
+                       "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
+                       "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
+            "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,
+            "decompress_GBps": round(u_bytes * world / (ms_d * 1e-3) / 1e9, 2) if world == 1 else None,
+            "roofline": r_c if ms_c >= ms_d else r_d,               # the dominant kernel
+            "roofline_compress": r_c, "roofline_decompress": r_d,
+            "verified": "decode(encode(x)) == x for every block, all status OK",
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ns = min(args.cpu_sample_blocks, nb)
+            line["cpu_baseline"] = cpu_baseline(raw[: ns * BLOCK].cpu().numpy(), variant)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

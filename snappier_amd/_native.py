@@ -1,0 +1,83 @@
+"""ctypes binding of libsnappier_hip.so -- the C-ABI declared in include/snappier_hip.h.
+
+The library is the product: if it is missing or a symbol is absent this module raises, there is no fallback.
+torch is imported first on purpose: torch bundles its own libamdhip64.so.7; loading it before our library makes
+the dynamic loader resolve our DT_NEEDED libamdhip64.so.7 to that same object, so torch tensors and our kernels
+share one HIP runtime (one context, one set of streams).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import torch  # noqa: F401  (must precede CDLL -- see module docstring)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsnappier_hip.so")
+HEADER_PATH = os.path.join(HERE, "..", "include", "snappier_hip.h")
+
+(OK, ERR_OUTPUT_TOO_SMALL, ERR_BAD_OFFSET, ERR_TOO_LONG, ERR_INCOMPLETE, ERR_BAD_LENGTH, ERR_CRC_MISMATCH,
+ ERR_CHUNK_TYPE, ERR_OVERLAP, ERR_BAD_ARG, ERR_DEVICE, ERR_TRUNCATED_STREAM) = range(12)
+HASH_CRC32C, HASH_MUL = 0, 1
+BLOCK_SIZE = 65536
+MAX_BLOCK_COMPRESSED = 76491
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/snappier_hip.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(snp_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m snappier_amd.build` "
+                          "(there is no CPU fallback for the codec)")
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    if missing:
+        raise ImportError(f"libsnappier_hip.so does not export: {missing}")
+    vp, sz, u32, u64, i32, i64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_int64
+    szp = C.POINTER(sz)
+    sig = {
+        "snp_ctx_create": (i32, [i32, i32, vp, C.POINTER(vp)]),
+        "snp_ctx_destroy": (None, [vp]),
+        "snp_ctx_last_error": (C.c_char_p, [vp]),
+        "snp_ctx_synchronize": (i32, [vp]),
+        "snp_status_string": (C.c_char_p, [i32]),
+        "snp_version": (C.c_char_p, []),
+        "snp_max_compressed_length": (i64, [i64]),
+        "snp_max_fragment_compressed_length": (i64, [i64]),
+        "snp_get_uncompressed_length": (i32, [vp, sz, C.POINTER(u32), C.POINTER(u32)]),
+        "snp_try_compress": (i32, [vp, vp, sz, vp, sz, szp]),
+        "snp_try_decompress": (i32, [vp, vp, sz, vp, sz, szp]),
+        "snp_crc32c": (i32, [vp, vp, sz, i32, C.POINTER(u32)]),
+        "snp_frame_max_encoded_length": (i64, [i64]),
+        "snp_frame_encode": (i32, [vp, vp, sz, vp, sz, szp]),
+        "snp_frame_decoded_length": (i32, [vp, sz, C.POINTER(u64)]),
+        "snp_frame_decode": (i32, [vp, vp, sz, vp, sz, szp]),
+        "snp_compress_batch": (i32, [vp, vp, vp, vp, u32, vp, vp, vp, vp]),
+        "snp_decompress_batch": (i32, [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp]),
+        "snp_crc32c_batch": (i32, [vp, vp, vp, vp, u32, i32, vp]),
+        "snp_frame_encode_workspace": (u64, [u64]),
+        "snp_frame_encode_device": (i32, [vp, vp, u64, vp, u64, vp, vp]),
+        "snp_frame_decode_chunks_device": (i32, [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def status_string(st: int) -> str:
+    return lib().snp_status_string(st).decode()

@@ -1,0 +1,58 @@
+"""Codec context: one HIP device + stream + reusable HBM scratch (snp_ctx).
+
+Snappy.* in the reference is re-entrant because each call news up a compressor (Snappy.cs:64,174,225); here each
+thread gets its own default Context instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+from . import _native as N
+from .errors import InvalidOperationException
+
+
+class Context:
+    def __init__(self, device: int = 0, hash_variant: int = N.HASH_CRC32C, stream: int | None = None):
+        """stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream) or None for a private stream."""
+        self._h = C.c_void_p()
+        st = N.lib().snp_ctx_create(device, hash_variant, C.c_void_p(stream) if stream else None, C.byref(self._h))
+        if st != N.OK:
+            self._h = C.c_void_p()
+            raise InvalidOperationException(
+                f"snp_ctx_create(device={device}) failed: {N.status_string(st)} -- the codec runs on a HIP device only")
+        self.device = device
+        self.hash_variant = hash_variant
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self):
+        st = N.lib().snp_ctx_synchronize(self._h)
+        if st != N.OK:
+            raise InvalidOperationException(N.lib().snp_ctx_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            N.lib().snp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_tls = threading.local()
+
+
+def default_context(hash_variant: int | None = None) -> Context:
+    key = N.HASH_CRC32C if hash_variant is None else hash_variant
+    cache = getattr(_tls, "ctx", None)
+    if cache is None:
+        cache = _tls.ctx = {}
+    if key not in cache:
+        cache[key] = Context(0, key)
+    return cache[key]

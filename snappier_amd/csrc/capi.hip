@@ -1,0 +1,543 @@
+// capi.hip -- the C-ABI of libsnappier_hip.so (include/snappier_hip.h): contexts, HBM scratch, host staging and
+// the launch sequences behind each entry point.  No codec arithmetic happens on the host: every byte of compress /
+// decompress / CRC work is done by the gfx950 kernels in compress.hip, decompress.hip, crc32c.hip, framing.hip.
+// There is no CPU fallback -- without a HIP device snp_ctx_create fails with SNP_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "snp_device.h"
+
+extern "C" {
+hipError_t snp_launch_decompress(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*,
+                                 const u8*, int, hipStream_t);
+hipError_t snp_launch_compress(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int,
+                               hipStream_t);
+hipError_t snp_launch_crc32c(const u8*, const u64*, const u32*, u32, int, u32*, const u32*, i32*, hipStream_t);
+hipError_t snp_launch_gather(const u8*, const u64*, const u32*, u8*, const u64*, u32, hipStream_t);
+hipError_t snp_launch_frame_chunks(u64, u32, u64, u64*, u32*, u64*, hipStream_t);
+hipError_t snp_launch_frame_plan(const u32*, const u32*, u32, u8*, u32*, u64*, u64*, hipStream_t);
+hipError_t snp_launch_frame_header_only(u8*, u64*, hipStream_t);
+hipError_t snp_launch_frame_emit(const u8*, const u64*, const u8*, const u64*, const u8*, const u32*, const u32*,
+                                 const u64*, u8*, u64, u32, hipStream_t);
+}
+
+namespace {
+
+constexpr u64 kCompStride = 76496 + 16;   // snp_max_compressed_length(65536), padded to a 16-byte multiple
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct snp_ctx {
+    int device = 0;
+    int variant = SNP_HASH_CRC32C;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int fenced = 0;          // SNAPPIER_HIP_FENCED=1: drain vmcnt before reading freshly written output (debug knob)
+    DevBuf in, out, meta, work;
+    std::string err;
+
+    bool check(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return true;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    }
+    bool ensure(DevBuf& b, size_t bytes, const char* what)
+    {
+        if (bytes <= b.cap) return true;
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        if (!check(hipMalloc(&b.p, want), what)) return false;
+        b.cap = want;
+        return true;
+    }
+    bool use_device() { return check(hipSetDevice(device), "hipSetDevice"); }
+};
+
+extern "C" {
+
+// ---- context ---------------------------------------------------------------------------------------------
+
+snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** out_ctx)
+{
+    if (!out_ctx || (hash_variant != SNP_HASH_CRC32C && hash_variant != SNP_HASH_MUL)) return SNP_ERR_BAD_ARG;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return SNP_ERR_DEVICE;
+    snp_ctx* c = new (std::nothrow) snp_ctx();
+    if (!c) return SNP_ERR_DEVICE;
+    c->device = device;
+    c->variant = hash_variant;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return SNP_ERR_DEVICE; }
+    if (stream) c->stream = static_cast<hipStream_t>(stream);
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SNP_ERR_DEVICE; }
+        c->own_stream = true;
+    }
+    const char* f = getenv("SNAPPIER_HIP_FENCED");
+    c->fenced = (f && f[0] == '1') ? 1 : 0;
+    *out_ctx = c;
+    return SNP_OK;
+}
+
+void snp_ctx_destroy(snp_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work})
+        if (b->p) (void)hipFree(b->p);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* snp_ctx_last_error(const snp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+snp_status snp_ctx_synchronize(snp_ctx* c)
+{
+    if (!c) return SNP_ERR_BAD_ARG;
+    return c->check(hipStreamSynchronize(c->stream), "hipStreamSynchronize") ? SNP_OK : SNP_ERR_DEVICE;
+}
+
+const char* snp_status_string(int s)
+{
+    switch (s) {
+        case SNP_OK: return "ok";
+        case SNP_ERR_OUTPUT_TOO_SMALL: return "Output buffer is too small.";
+        case SNP_ERR_BAD_OFFSET: return "Invalid copy offset";
+        case SNP_ERR_TOO_LONG: return "Data too long";
+        case SNP_ERR_INCOMPLETE: return "Incomplete Snappy block.";
+        case SNP_ERR_BAD_LENGTH: return "Invalid stream length";
+        case SNP_ERR_CRC_MISMATCH: return "Chunk CRC mismatch.";
+        case SNP_ERR_CHUNK_TYPE: return "Unknown chunk type";
+        case SNP_ERR_OVERLAP: return "Input and output spans must not overlap.";
+        case SNP_ERR_BAD_ARG: return "bad argument";
+        case SNP_ERR_DEVICE: return "HIP device error";
+        case SNP_ERR_TRUNCATED_STREAM: return "truncated framed stream";
+        default: return "unknown status";
+    }
+}
+
+const char* snp_version(void) { return "snappier_hip 0.1 (gfx950)"; }
+
+// ---- host-only arithmetic --------------------------------------------------------------------------------
+
+int64_t snp_max_fragment_compressed_length(int64_t n)   // Helpers.MaxCompressedLength  Helpers.cs:17-46
+{
+    if (n < 0) return -1;
+    return 32 + n + n / 6 + 1;
+}
+
+int64_t snp_max_compressed_length(int64_t n)            // Snappy.GetMaxCompressedLength  Snappy.cs:20-24
+{
+    if (n < 0) return -1;
+    const int64_t v = snp_max_fragment_compressed_length(n) + SNP_VARINT_MAX;
+    return v > 0x7fffffffLL ? -1 : v;
+}
+
+// VarIntEncoding.TryReadSlow  VarIntEncoding.Read.cs:38-79 ; anything but Done is "Invalid stream length" (:16-24)
+snp_status snp_get_uncompressed_length(const uint8_t* in, size_t n, uint32_t* out_len, uint32_t* out_header_bytes)
+{
+    if (!in && n) return SNP_ERR_BAD_ARG;
+    u32 result = 0;
+    int shift = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const u8 c = in[i];
+        const u32 val = c & 0x7fu;
+        if (val & ~(0xffffffffu >> shift)) return SNP_ERR_BAD_LENGTH;
+        result |= val << shift;
+        shift += 7;
+        if (c < 128) {
+            if (out_len) *out_len = result;
+            if (out_header_bytes) *out_header_bytes = static_cast<u32>(i + 1);
+            return SNP_OK;
+        }
+        if (shift >= 32) return SNP_ERR_BAD_LENGTH;
+    }
+    return SNP_ERR_BAD_LENGTH;
+}
+
+int64_t snp_frame_max_encoded_length(int64_t n)
+{
+    if (n < 0) return -1;
+    const int64_t chunks = (n + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
+    return SNP_STREAM_HEADER_LEN + chunks * SNP_CHUNK_HEADER_LEN + n;   // a chunk never grows (type 0x01 fallback)
+}
+
+// ---- batch, device pointers --------------------------------------------------------------------------------
+
+snp_status snp_compress_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                              uint32_t nblocks, uint8_t* out, const uint64_t* out_off, uint32_t* out_len,
+                              int32_t* status)
+{
+    if (!c || (nblocks && (!in || !in_off || !in_len || !out || !out_off || !out_len || !status))) return SNP_ERR_BAD_ARG;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    return c->check(snp_launch_compress(in, in_off, in_len, nblocks, out, out_off, out_len, status, c->variant, 1,
+                                        c->stream), "compress launch") ? SNP_OK : SNP_ERR_DEVICE;
+}
+
+snp_status snp_decompress_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                                uint32_t nblocks, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
+                                uint32_t* out_len, int32_t* status)
+{
+    if (!c || (nblocks && (!in || !in_off || !in_len || !out || !out_off || !out_cap || !out_len || !status)))
+        return SNP_ERR_BAD_ARG;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    return c->check(snp_launch_decompress(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, nullptr,
+                                          c->fenced, c->stream), "decompress launch") ? SNP_OK : SNP_ERR_DEVICE;
+}
+
+snp_status snp_crc32c_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                            uint32_t nblocks, int masked, uint32_t* out_crc)
+{
+    if (!c || (nblocks && (!in || !in_off || !in_len || !out_crc))) return SNP_ERR_BAD_ARG;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    return c->check(snp_launch_crc32c(in, in_off, in_len, nblocks, masked, out_crc, nullptr, nullptr, c->stream),
+                    "crc32c launch") ? SNP_OK : SNP_ERR_DEVICE;
+}
+
+// workspace layout for snp_frame_encode_device (all sub-arrays 16-byte aligned)
+struct FrameWork {
+    u64 *in_off, *comp_off, *dst_off, *total;
+    u32 *in_len, *comp_len, *payload, *crc;
+    i32* status;
+    u8 *type, *comp;
+    u64 bytes;
+};
+static FrameWork frame_work_layout(void* base, u64 n)
+{
+    const u64 nc = (n + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
+    u8* p = static_cast<u8*>(base);
+    u64 o = 0;
+    FrameWork w{};
+    auto take = [&](u64 bytes) { u8* r = p ? p + o : nullptr; o += align_up(bytes, 16); return r; };
+    w.in_off = reinterpret_cast<u64*>(take(nc * 8));
+    w.comp_off = reinterpret_cast<u64*>(take(nc * 8));
+    w.dst_off = reinterpret_cast<u64*>(take((nc + 1) * 8));
+    w.total = reinterpret_cast<u64*>(take(8));
+    w.in_len = reinterpret_cast<u32*>(take(nc * 4));
+    w.comp_len = reinterpret_cast<u32*>(take(nc * 4));
+    w.payload = reinterpret_cast<u32*>(take(nc * 4));
+    w.crc = reinterpret_cast<u32*>(take(nc * 4));
+    w.status = reinterpret_cast<i32*>(take(nc * 4));
+    w.type = take(nc);
+    w.comp = take(nc * kCompStride);
+    w.bytes = o;
+    return w;
+}
+
+uint64_t snp_frame_encode_workspace(uint64_t n) { return frame_work_layout(nullptr, n).bytes; }
+
+snp_status snp_frame_encode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap,
+                                   uint64_t* d_written, void* d_work)
+{
+    if (!c || !d_out || !d_written || !d_work || (n && !d_in)) return SNP_ERR_BAD_ARG;
+    if (n > 0xffffffffull * SNP_BLOCK_SIZE) return SNP_ERR_BAD_ARG;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    if (cap < SNP_STREAM_HEADER_LEN) return SNP_ERR_OUTPUT_TOO_SMALL;
+    const u32 nc = static_cast<u32>((n + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE);
+    hipStream_t s = c->stream;
+    if (nc == 0)
+        return c->check(snp_launch_frame_header_only(d_out, d_written, s), "frame header") ? SNP_OK : SNP_ERR_DEVICE;
+    const FrameWork w = frame_work_layout(d_work, n);
+    bool ok = c->check(snp_launch_frame_chunks(n, nc, kCompStride, w.in_off, w.in_len, w.comp_off, s), "frame chunks");
+    // CompressBlock: TryCompress(chunk) = varint + one fragment  (SnappyStreamCompressor.cs:206)
+    ok = ok && c->check(snp_launch_compress(d_in, w.in_off, w.in_len, nc, w.comp, w.comp_off, w.comp_len, w.status,
+                                            c->variant, 1, s), "frame compress");
+    // masked CRC-32C of the RAW chunk  (:243-245,258-260)
+    ok = ok && c->check(snp_launch_crc32c(d_in, w.in_off, w.in_len, nc, 1, w.crc, nullptr, nullptr, s), "frame crc");
+    ok = ok && c->check(snp_launch_frame_plan(w.in_len, w.comp_len, nc, w.type, w.payload, w.dst_off, d_written, s),
+                        "frame plan");
+    ok = ok && c->check(snp_launch_frame_emit(d_in, w.in_off, w.comp, w.comp_off, w.type, w.payload, w.crc, w.dst_off,
+                                              d_out, cap, nc, s), "frame emit");
+    return ok ? SNP_OK : SNP_ERR_DEVICE;
+}
+
+snp_status snp_frame_decode_chunks_device(snp_ctx* c, const uint8_t* d_in, const uint8_t* chunk_type,
+                                          const uint64_t* body_off, const uint32_t* body_len,
+                                          const uint32_t* chunk_crc, uint32_t nchunks, uint8_t* d_out,
+                                          const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
+                                          int32_t* status)
+{
+    if (!c || (nchunks && (!d_in || !chunk_type || !body_off || !body_len || !chunk_crc || !d_out || !out_off ||
+                           !out_cap || !out_len || !status)))
+        return SNP_ERR_BAD_ARG;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    hipStream_t s = c->stream;
+    bool ok = c->check(snp_launch_decompress(d_in, body_off, body_len, nchunks, d_out, out_off, out_cap, out_len, status,
+                                             chunk_type, c->fenced, s), "frame decode");
+    // CRC over the produced bytes, compared with the chunk's stored masked CRC  (SnappyStreamDecompressor.cs:117-131)
+    ok = ok && c->check(snp_launch_crc32c(d_out, out_off, out_len, nchunks, 1, nullptr, chunk_crc, status, s),
+                        "frame crc verify");
+    return ok ? SNP_OK : SNP_ERR_DEVICE;
+}
+
+// ---- single-buffer, host pointers --------------------------------------------------------------------------
+
+static bool ranges_overlap(const u8* a, size_t an, const u8* b, size_t bn)
+{
+    return an && bn && a < b + bn && b < a + an;
+}
+
+snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written)
+{
+    if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    *written = 0;
+    if (n > 0xffffffffull) return SNP_ERR_BAD_ARG;                       // SnappyCompressor.cs:88-91
+    if (cap == 0) return SNP_ERR_OUTPUT_TOO_SMALL;                        // Snappy.cs:57-62
+    if (ranges_overlap(in, n, out, cap)) return SNP_ERR_OVERLAP;          // SnappyCompressor.cs:27-30
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+
+    u8 hdr[SNP_VARINT_MAX];                                               // VarIntEncoding.TryWrite  :34-37
+    u32 hb = 0;
+    for (u32 v = static_cast<u32>(n);;) {
+        if (v < 128) { hdr[hb++] = static_cast<u8>(v); break; }
+        hdr[hb++] = static_cast<u8>(v | 0x80);
+        v >>= 7;
+    }
+    if (cap < hb) return SNP_ERR_OUTPUT_TOO_SMALL;
+    const u32 nf = static_cast<u32>((n + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE);
+    if (nf == 0) { memcpy(out, hdr, hb); *written = hb; return SNP_OK; }
+
+    hipStream_t s = c->stream;
+    // meta: in_off, comp_off, dst_off (u64) ; in_len, comp_len (u32) ; status (i32)
+    const u64 meta_bytes = static_cast<u64>(nf) * (8 * 3 + 4 * 3);
+    if (!c->ensure(c->in, n, "hipMalloc(in)") || !c->ensure(c->work, nf * kCompStride, "hipMalloc(work)") ||
+        !c->ensure(c->meta, meta_bytes, "hipMalloc(meta)"))
+        return SNP_ERR_DEVICE;
+    u64* d_in_off = static_cast<u64*>(c->meta.p);
+    u64* d_comp_off = d_in_off + nf;
+    u64* d_dst_off = d_comp_off + nf;
+    u32* d_in_len = reinterpret_cast<u32*>(d_dst_off + nf);
+    u32* d_comp_len = d_in_len + nf;
+    i32* d_status = reinterpret_cast<i32*>(d_comp_len + nf);
+
+    bool ok = c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    ok = ok && c->check(snp_launch_frame_chunks(n, nf, kCompStride, d_in_off, d_in_len, d_comp_off, s), "fragment table");
+    ok = ok && c->check(snp_launch_compress(static_cast<const u8*>(c->in.p), d_in_off, d_in_len, nf,
+                                            static_cast<u8*>(c->work.p), d_comp_off, d_comp_len, d_status, c->variant,
+                                            0, s), "compress");
+    std::vector<u32> comp_len(nf);
+    ok = ok && c->check(hipMemcpyAsync(comp_len.data(), d_comp_len, nf * 4ull, hipMemcpyDeviceToHost, s), "D2H lengths");
+    ok = ok && c->check(hipStreamSynchronize(s), "sync");
+    if (!ok) return SNP_ERR_DEVICE;
+
+    std::vector<u64> dst_off(nf);
+    u64 total = 0;
+    for (u32 f = 0; f < nf; ++f) { dst_off[f] = total; total += comp_len[f]; }
+    if (cap - hb < total) return SNP_ERR_OUTPUT_TOO_SMALL;                 // SnappyCompressor.cs:63-68
+    if (!c->ensure(c->out, total, "hipMalloc(out)")) return SNP_ERR_DEVICE;
+    ok = c->check(hipMemcpyAsync(d_dst_off, dst_off.data(), nf * 8ull, hipMemcpyHostToDevice, s), "H2D offsets");
+    ok = ok && c->check(snp_launch_gather(static_cast<const u8*>(c->work.p), d_comp_off, d_comp_len,
+                                          static_cast<u8*>(c->out.p), d_dst_off, nf, s), "gather");
+    ok = ok && c->check(hipMemcpyAsync(out + hb, c->out.p, total, hipMemcpyDeviceToHost, s), "D2H output");
+    ok = ok && c->check(hipStreamSynchronize(s), "sync");
+    if (!ok) return SNP_ERR_DEVICE;
+    memcpy(out, hdr, hb);
+    *written = hb + total;
+    return SNP_OK;
+}
+
+snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written)
+{
+    if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    *written = 0;
+    if (n > 0xffffffffull) return SNP_ERR_BAD_ARG;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    hipStream_t s = c->stream;
+    const u32 cap32 = cap > 0x7fffffffull ? 0x7fffffffu : static_cast<u32>(cap);
+    if (!c->ensure(c->in, n + 16, "hipMalloc(in)") || !c->ensure(c->out, static_cast<size_t>(cap32) + 16, "hipMalloc(out)") ||
+        !c->ensure(c->meta, 64, "hipMalloc(meta)"))
+        return SNP_ERR_DEVICE;
+    struct Meta { u64 in_off, out_off; u32 in_len, out_cap, out_len; i32 status; } h{0, 0, static_cast<u32>(n), cap32, 0, 0};
+    u8* m = static_cast<u8*>(c->meta.p);
+    bool ok = c->check(hipMemcpyAsync(m, &h, sizeof(h), hipMemcpyHostToDevice, s), "H2D meta");
+    if (n) ok = ok && c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    ok = ok && c->check(snp_launch_decompress(static_cast<const u8*>(c->in.p), reinterpret_cast<u64*>(m + offsetof(Meta, in_off)),
+                                              reinterpret_cast<u32*>(m + offsetof(Meta, in_len)), 1,
+                                              static_cast<u8*>(c->out.p), reinterpret_cast<u64*>(m + offsetof(Meta, out_off)),
+                                              reinterpret_cast<u32*>(m + offsetof(Meta, out_cap)),
+                                              reinterpret_cast<u32*>(m + offsetof(Meta, out_len)),
+                                              reinterpret_cast<i32*>(m + offsetof(Meta, status)), nullptr, c->fenced, s),
+                        "decompress");
+    ok = ok && c->check(hipMemcpyAsync(&h, m, sizeof(h), hipMemcpyDeviceToHost, s), "D2H meta");
+    ok = ok && c->check(hipStreamSynchronize(s), "sync");
+    if (!ok) return SNP_ERR_DEVICE;
+    if (h.status != SNP_OK) return static_cast<snp_status>(h.status);
+    if (h.out_len) {
+        ok = c->check(hipMemcpyAsync(out, c->out.p, h.out_len, hipMemcpyDeviceToHost, s), "D2H output") &&
+             c->check(hipStreamSynchronize(s), "sync");
+        if (!ok) return SNP_ERR_DEVICE;
+    }
+    *written = h.out_len;
+    return SNP_OK;
+}
+
+snp_status snp_crc32c(snp_ctx* c, const uint8_t* in, size_t n, int masked, uint32_t* out_crc)
+{
+    if (!c || !out_crc || (n && !in)) return SNP_ERR_BAD_ARG;
+    if (n > 0xffffffffull) return SNP_ERR_BAD_ARG;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    hipStream_t s = c->stream;
+    if (!c->ensure(c->in, n + 16, "hipMalloc(in)") || !c->ensure(c->meta, 64, "hipMalloc(meta)")) return SNP_ERR_DEVICE;
+    struct Meta { u64 off; u32 len, crc; } h{0, static_cast<u32>(n), 0};
+    u8* m = static_cast<u8*>(c->meta.p);
+    bool ok = c->check(hipMemcpyAsync(m, &h, sizeof(h), hipMemcpyHostToDevice, s), "H2D meta");
+    if (n) ok = ok && c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    ok = ok && c->check(snp_launch_crc32c(static_cast<const u8*>(c->in.p), reinterpret_cast<u64*>(m), reinterpret_cast<u32*>(m + 8),
+                                          1, masked, reinterpret_cast<u32*>(m + 12), nullptr, nullptr, s), "crc32c");
+    ok = ok && c->check(hipMemcpyAsync(&h, m, sizeof(h), hipMemcpyDeviceToHost, s), "D2H meta");
+    ok = ok && c->check(hipStreamSynchronize(s), "sync");
+    if (!ok) return SNP_ERR_DEVICE;
+    *out_crc = h.crc;
+    return SNP_OK;
+}
+
+snp_status snp_frame_encode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written)
+{
+    if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    *written = 0;
+    if (ranges_overlap(in, n, out, cap)) return SNP_ERR_OVERLAP;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    hipStream_t s = c->stream;
+    const u64 max_out = static_cast<u64>(snp_frame_max_encoded_length(static_cast<int64_t>(n)));
+    const u64 wbytes = snp_frame_encode_workspace(n);
+    if (!c->ensure(c->in, n + 16, "hipMalloc(in)") || !c->ensure(c->out, max_out + 16, "hipMalloc(out)") ||
+        !c->ensure(c->work, wbytes + 16, "hipMalloc(work)") || !c->ensure(c->meta, 64, "hipMalloc(meta)"))
+        return SNP_ERR_DEVICE;
+    bool ok = true;
+    if (n) ok = c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    if (!ok) return SNP_ERR_DEVICE;
+    snp_status st = snp_frame_encode_device(c, static_cast<const u8*>(c->in.p), n, static_cast<u8*>(c->out.p), max_out,
+                                            static_cast<u64*>(c->meta.p), c->work.p);
+    if (st != SNP_OK) return st;
+    u64 total = 0;
+    ok = c->check(hipMemcpyAsync(&total, c->meta.p, 8, hipMemcpyDeviceToHost, s), "D2H total") &&
+         c->check(hipStreamSynchronize(s), "sync");
+    if (!ok) return SNP_ERR_DEVICE;
+    if (total > cap) return SNP_ERR_OUTPUT_TOO_SMALL;
+    ok = c->check(hipMemcpyAsync(out, c->out.p, total, hipMemcpyDeviceToHost, s), "D2H output") &&
+         c->check(hipStreamSynchronize(s), "sync");
+    if (!ok) return SNP_ERR_DEVICE;
+    *written = total;
+    return SNP_OK;
+}
+
+// Host-side walk over chunk headers only (SnappyStreamDecompressor.ReadChunkHeader  :215-254): 4 bytes per chunk.
+struct ChunkScan {
+    std::vector<u8> type;
+    std::vector<u64> body_off, out_off;
+    std::vector<u32> body_len, crc, out_cap;
+    u64 total = 0;
+    snp_status tail = SNP_OK;   // error met after the chunks listed above (they are still decoded and checked first)
+};
+static void scan_chunks(const u8* in, size_t n, ChunkScan& cs)
+{
+    size_t ip = 0;
+    while (ip < n) {
+        if (n - ip < 4) { cs.tail = SNP_ERR_TRUNCATED_STREAM; return; }
+        const u32 type = in[ip];
+        const u32 size = in[ip + 1] | (in[ip + 2] << 8) | (static_cast<u32>(in[ip + 3]) << 16);   // :64-65
+        ip += 4;
+        if (n - ip < size) { cs.tail = SNP_ERR_TRUNCATED_STREAM; return; }
+        if (type == 0x00 || type == 0x01) {
+            if (size < 4) { cs.tail = SNP_ERR_TRUNCATED_STREAM; return; }
+            u32 crc;
+            memcpy(&crc, in + ip, 4);                                    // ReadChunkCrc  :260-289
+            u32 dec = size - 4, hb = 0;
+            if (type == 0x00 && snp_get_uncompressed_length(in + ip + 4, size - 4, &dec, &hb) != SNP_OK) {
+                cs.tail = SNP_ERR_BAD_LENGTH;
+                return;
+            }
+            if (dec > 0x7fffffffu) { cs.tail = SNP_ERR_BAD_LENGTH; return; }
+            cs.type.push_back(static_cast<u8>(type));
+            cs.body_off.push_back(ip + 4);
+            cs.body_len.push_back(size - 4);
+            cs.crc.push_back(crc);
+            cs.out_off.push_back(cs.total);
+            cs.out_cap.push_back(dec);
+            cs.total += dec;
+        } else if (type < 0x80) {                                        // :182-185
+            cs.tail = SNP_ERR_CHUNK_TYPE;
+            return;
+        }                                                                // 0x80..0xff skipped unvalidated  :187-196
+        ip += size;
+    }
+}
+
+snp_status snp_frame_decoded_length(const uint8_t* in, size_t n, uint64_t* out_len)
+{
+    if (!out_len || (n && !in)) return SNP_ERR_BAD_ARG;
+    ChunkScan cs;
+    scan_chunks(in, n, cs);
+    *out_len = cs.total;
+    return cs.tail;
+}
+
+snp_status snp_frame_decode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written)
+{
+    if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    *written = 0;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    ChunkScan cs;
+    scan_chunks(in, n, cs);
+    const u32 nc = static_cast<u32>(cs.type.size());
+    if (cs.total > cap) return SNP_ERR_OUTPUT_TOO_SMALL;
+    if (nc == 0) return cs.tail;
+    hipStream_t s = c->stream;
+    // meta: body_off, out_off (u64) ; body_len, crc, out_cap, out_len (u32) ; status (i32) ; type (u8)
+    const u64 meta_bytes = static_cast<u64>(nc) * (8 * 2 + 4 * 5 + 1) + 64;
+    if (!c->ensure(c->in, n + 16, "hipMalloc(in)") || !c->ensure(c->out, cs.total + 16, "hipMalloc(out)") ||
+        !c->ensure(c->meta, meta_bytes, "hipMalloc(meta)"))
+        return SNP_ERR_DEVICE;
+    u64* d_body_off = static_cast<u64*>(c->meta.p);
+    u64* d_out_off = d_body_off + nc;
+    u32* d_body_len = reinterpret_cast<u32*>(d_out_off + nc);
+    u32* d_crc = d_body_len + nc;
+    u32* d_out_cap = d_crc + nc;
+    u32* d_out_len = d_out_cap + nc;
+    i32* d_status = reinterpret_cast<i32*>(d_out_len + nc);
+    u8* d_type = reinterpret_cast<u8*>(d_status + nc);
+    bool ok = c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    ok = ok && c->check(hipMemcpyAsync(d_body_off, cs.body_off.data(), nc * 8ull, hipMemcpyHostToDevice, s), "H2D meta");
+    ok = ok && c->check(hipMemcpyAsync(d_out_off, cs.out_off.data(), nc * 8ull, hipMemcpyHostToDevice, s), "H2D meta");
+    ok = ok && c->check(hipMemcpyAsync(d_body_len, cs.body_len.data(), nc * 4ull, hipMemcpyHostToDevice, s), "H2D meta");
+    ok = ok && c->check(hipMemcpyAsync(d_crc, cs.crc.data(), nc * 4ull, hipMemcpyHostToDevice, s), "H2D meta");
+    ok = ok && c->check(hipMemcpyAsync(d_out_cap, cs.out_cap.data(), nc * 4ull, hipMemcpyHostToDevice, s), "H2D meta");
+    ok = ok && c->check(hipMemcpyAsync(d_type, cs.type.data(), nc, hipMemcpyHostToDevice, s), "H2D meta");
+    if (!ok) return SNP_ERR_DEVICE;
+    snp_status st = snp_frame_decode_chunks_device(c, static_cast<const u8*>(c->in.p), d_type, d_body_off, d_body_len,
+                                                   d_crc, nc, static_cast<u8*>(c->out.p), d_out_off, d_out_cap, d_out_len,
+                                                   d_status);
+    if (st != SNP_OK) return st;
+    std::vector<i32> status(nc);
+    ok = c->check(hipMemcpyAsync(status.data(), d_status, nc * 4ull, hipMemcpyDeviceToHost, s), "D2H status") &&
+         c->check(hipStreamSynchronize(s), "sync");
+    if (!ok) return SNP_ERR_DEVICE;
+    for (u32 i = 0; i < nc; ++i)                                          // first failing chunk in stream order wins,
+        if (status[i] != SNP_OK) return static_cast<snp_status>(status[i]);   // as the sequential reference would throw
+    if (cs.tail != SNP_OK) return cs.tail;
+    if (cs.total) {
+        ok = c->check(hipMemcpyAsync(out, c->out.p, cs.total, hipMemcpyDeviceToHost, s), "D2H output") &&
+             c->check(hipStreamSynchronize(s), "sync");
+        if (!ok) return SNP_ERR_DEVICE;
+    }
+    *written = cs.total;
+    return SNP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// snp_device.h -- shared device-side helpers for the gfx950 Snappy block codec kernels.
+// One 64-lane wavefront owns one Snappy block; everything here is wave-level (no __syncthreads anywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/snappier_hip.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+
+#define SNP_WAVE 64
+
+// Unaligned little-endian accesses.  gfx950 under HSA runs in unaligned-access mode, so a dword access at any byte
+// address is one global_load_dword / global_store_dword (the packed struct tells the compiler align = 1).
+struct __attribute__((packed)) snp_u32_unaligned { u32 v; };
+struct __attribute__((packed)) snp_u64_unaligned { u64 v; };
+struct __attribute__((packed)) snp_u128_unaligned { u32 v[4]; };
+
+__device__ __forceinline__ u32 ld32u(const u8* p) { return reinterpret_cast<const snp_u32_unaligned*>(p)->v; }
+__device__ __forceinline__ u64 ld64u(const u8* p) { return reinterpret_cast<const snp_u64_unaligned*>(p)->v; }
+__device__ __forceinline__ void st32u(u8* p, u32 v) { reinterpret_cast<snp_u32_unaligned*>(p)->v = v; }
+
+__device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ u32 bcast_first(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u32 read_lane(u32 v, u32 lane) { return __builtin_amdgcn_readlane(v, lane); }
+// 64-bit masks: lanes strictly below `lane`
+__device__ __forceinline__ u64 lanes_below(u32 lane) { return lane >= 64 ? ~0ull : ((1ull << lane) - 1ull); }
+
+// Wave-wide memcpy for a wave-uniform (dst, src, len): 16 B per lane per step while a full 1 KiB remains, then
+// 4 B per lane, then a byte tail.  src and dst must not overlap.  All lanes must call it.
+__device__ __forceinline__ void wave_copy(u8* dst, const u8* src, u32 len, u32 lane)
+{
+    u32 done = 0;
+    while (len - done >= 1024) {
+        snp_u128_unaligned w = *reinterpret_cast<const snp_u128_unaligned*>(src + done + lane * 16);
+        *reinterpret_cast<snp_u128_unaligned*>(dst + done + lane * 16) = w;
+        done += 1024;
+    }
+    while (len - done >= 256) {
+        st32u(dst + done + lane * 4, ld32u(src + done + lane * 4));
+        done += 256;
+    }
+    for (u32 k = done + lane; k < len; k += 64) dst[k] = src[k];
+}
+
+// Framing mask  Crc32CAlgorithm.ApplyMask  (Snappier/Internal/Crc32CAlgorithm.cs:156-158)
+__host__ __device__ __forceinline__ u32 crc32c_mask(u32 x) { return ((x >> 15) | (x << 17)) + 0xa282ead8u; }

@@ -43,22 +43,32 @@ def mix64(z: int) -> int:
     return z ^ (z >> 31)
 
 
-def html_like_blocks(html: bytes, first_block: int, nblocks: int, block: int = 65536) -> np.ndarray:
-    """Config 2: block b = html tiled cyclically from offset (b*4099) mod len(html); byte q of the block is then
-    decided by draw q of the block's splitmix64 stream (seed HTML_SEED ^ b, i.e. r = mix64(seed + (q+1)*GAMMA)):
-    if r % 100 == 0 the byte is replaced by (r >> 32) & 0xff  (~1 % mutations).
+MIXED_SEED = 0x5EED0005
+
+
+def corpus_blocks(files, first_block: int, nblocks: int, seed: int, block: int = 65536) -> np.ndarray:
+    """Configs 2 and 5: block b takes file f = b mod len(files), tiles it cyclically from offset (b*4099) mod len_f;
+    byte q of the block is then decided by draw q of the block's splitmix64 stream (seed ^ b), i.e.
+    r = mix64((seed ^ b) + (q+1)*GAMMA): if r % 100 == 0 the byte is replaced by (r >> 32) & 0xff (~1 % mutations).
     Same arithmetic as the device generator (snappier_amd/csrc/datagen.hip)."""
-    src = np.frombuffer(html, dtype=np.uint8)
-    L = len(src)
-    b = np.arange(first_block, first_block + nblocks, dtype=np.uint64)
-    start = (b * np.uint64(4099)) % np.uint64(L)
-    idx = (start[:, None] + np.arange(block, dtype=np.uint64)[None, :]) % np.uint64(L)
-    out = src[idx.astype(np.int64)]
-    r = splitmix64_vec(np.uint64(HTML_SEED) ^ b, block)
+    out = np.empty((nblocks, block), dtype=np.uint8)
+    q = np.arange(block, dtype=np.uint64)
+    for i in range(nblocks):
+        b = first_block + i
+        src = np.frombuffer(files[b % len(files)], dtype=np.uint8)
+        L = len(src)
+        start = (b * 4099) % L
+        out[i] = src[((np.uint64(start) + q) % np.uint64(L)).astype(np.int64)]
+    bb = np.arange(first_block, first_block + nblocks, dtype=np.uint64)
+    r = splitmix64_vec(np.uint64(seed) ^ bb, block)
     mut = (r % np.uint64(100)) == 0
     val = ((r >> np.uint64(32)) & np.uint64(0xFF)).astype(np.uint8)
-    out = np.where(mut, val, out)
-    return np.ascontiguousarray(out.reshape(-1))
+    return np.ascontiguousarray(np.where(mut, val, out).reshape(-1))
+
+
+def html_like_blocks(html: bytes, first_block: int, nblocks: int, block: int = 65536) -> np.ndarray:
+    """Config 2 = corpus_blocks over the single html fixture with HTML_SEED."""
+    return corpus_blocks([html], first_block, nblocks, HTML_SEED, block)
 
 
 PERIODS = [1, 2, 3, 4, 7, 8, 16, 64]

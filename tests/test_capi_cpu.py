@@ -1,0 +1,80 @@
+"""CPU-side checks of the drop-in boundary: libsnappier_hip.so loads, exports every symbol include/snappier_hip.h
+declares, its host-only arithmetic matches the reference KATs, and it FAILS LOUDLY without a HIP device
+(no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import kats
+from conftest import ROOT, read_testdata
+
+
+def test_library_built_and_exports_every_declared_symbol():
+    from snappier_amd import _native as N
+    assert os.path.exists(N.LIB_PATH), "run python -m snappier_amd.build"
+    declared = N.declared_symbols()
+    assert len(declared) >= 20 and "snp_compress_batch" in declared and "snp_decompress_batch" in declared
+    L = C.CDLL(N.LIB_PATH)
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "snappier_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in text and "from oracle" not in text and "libsnappy_oracle" not in text, f
+
+
+def test_host_only_arithmetic():
+    import snappier_amd as S
+    L = S.lib()
+    assert L.snp_max_compressed_length(65536) == 76496 and L.snp_max_fragment_compressed_length(65536) == 76491
+    assert L.snp_max_compressed_length(0) == 38 and L.snp_max_compressed_length(-1) == -1
+    assert L.snp_frame_max_encoded_length(0) == 10 and L.snp_frame_max_encoded_length(65537) == 10 + 16 + 65537
+    for value, enc in kats.VARINT:
+        if value <= 0x7FFFFFFF or True:
+            assert S.Snappy.GetUncompressedLength(enc + b"\xff" * 3) == value
+    for enc in kats.VARINT_INCOMPLETE + [kats.VARINT_BAD, b""]:
+        with pytest.raises(S.InvalidDataException):
+            S.Snappy.GetUncompressedLength(enc)
+    for name, declared in (("baddata1.snappy", 128082), ("baddata2.snappy", 128059), ("baddata3.snappy", 130378)):
+        assert S.Snappy.GetUncompressedLength(read_testdata(name)) == declared
+
+
+def test_frame_decoded_length_on_goldens():
+    import snappier_amd as S
+    for name, n in (("html_x_4.snappy", 409600), ("alice29.snappy", 152089)):
+        d = np.frombuffer(read_testdata(name), dtype=np.uint8)
+        v = C.c_uint64(0)
+        assert S.lib().snp_frame_decoded_length(C.c_void_p(d.ctypes.data), d.size, C.byref(v)) == 0
+        assert v.value == n
+    bad = np.frombuffer(read_testdata("html_x_4.snappy")[:10] + bytes([0x02, 1, 0, 0, 0]), dtype=np.uint8)
+    v = C.c_uint64(0)
+    assert S.lib().snp_frame_decoded_length(C.c_void_p(bad.ctypes.data), bad.size, C.byref(v)) == S._native.ERR_CHUNK_TYPE
+
+
+def test_fails_loudly_without_a_device():
+    import torch
+    import snappier_amd as S
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(S.InvalidOperationException):
+        S.Context()
+    with pytest.raises(S.InvalidOperationException):
+        S.Snappy.CompressToArray(b"hello")          # no CPU fallback behind the API
+
+
+def test_status_strings_match_reference_messages():
+    import snappier_amd as S
+    N = S._native
+    assert S.status_string(N.ERR_BAD_OFFSET) == "Invalid copy offset"                 # SnappyDecompressor.cs:600
+    assert S.status_string(N.ERR_TOO_LONG) == "Data too long"                         # :572,605
+    assert S.status_string(N.ERR_INCOMPLETE) == "Incomplete Snappy block."            # ThrowHelper.cs
+    assert S.status_string(N.ERR_BAD_LENGTH) == "Invalid stream length"               # VarIntEncoding.Read.cs:20
+    assert S.status_string(N.ERR_CRC_MISMATCH) == "Chunk CRC mismatch."               # SnappyStreamDecompressor.cs:130
+    assert S.status_string(N.ERR_OUTPUT_TOO_SMALL) == "Output buffer is too small."   # ThrowHelper.cs:18-19

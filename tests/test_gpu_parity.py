@@ -1,0 +1,457 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same inputs, bit-exact.
+Mirrors Snappier.Tests/SnappyTests.cs, SnappyStreamTests.cs, Internal/*Tests.cs for the hot path.  Needs an MI355X."""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import CORPUS, GOLDEN, ROOT, read_testdata
+import datagen
+import kats
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import snappier_amd as S
+    from snappier_amd import batch as SB, datagen as SD
+    Snappy = S.Snappy
+
+VARIANTS = [O.HASH_CRC32C, O.HASH_MUL]
+OUTDIR = os.path.join(ROOT, "gpurun_out")
+
+
+def ctx_for(variant):
+    return S.default_context(variant)
+
+
+def dump_mismatch(tag, got: bytes, ref: bytes):
+    os.makedirs(OUTDIR, exist_ok=True)
+    i = next((k for k, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
+    msg = f"{tag}: len got {len(got)} ref {len(ref)} first diff at {i}: got {got[i:i+16].hex()} ref {ref[i:i+16].hex()}"
+    with open(os.path.join(OUTDIR, "mismatch.log"), "a") as f:
+        f.write(msg + "\n")
+    return msg
+
+
+def assert_same(tag, got: bytes, ref: bytes):
+    if got != ref:
+        pytest.fail(dump_mismatch(tag, got, ref))
+
+
+@pytest.fixture(scope="module")
+def codec():
+    return {v: SB.BlockCodec(0, v) for v in VARIANTS}
+
+
+def to_dev(a: np.ndarray):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def blocks_of(data: bytes):
+    """-> (concatenated u8 array, in_off, in_len) for consecutive 64 KiB windows of data."""
+    n = len(data)
+    nb = max(1, (n + 65535) // 65536)
+    off = np.arange(nb, dtype=np.int64) * 65536
+    ln = np.minimum(65536, n - off).astype(np.int32)
+    return np.frombuffer(data, dtype=np.uint8), off, ln
+
+
+# ------------------------------------------------------------------ decompress
+
+@pytest.mark.parametrize("name", ["html_x_4.snappy", "alice29.snappy"])
+def test_decompress_golden_chunks(name):
+    from test_oracle_golden import parse_frames
+    for _t, crc, body in parse_frames(read_testdata(name)):
+        ref = O.decompress(body)
+        assert_same(name, Snappy.DecompressToArray(body), ref)
+        assert S.crc32c(ref, masked=True) == crc
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("name", CORPUS)
+def test_decompress_corpus_whole_files(name, variant):            # SnappyTests.cs:8-39 (decode side; multi-fragment blocks)
+    data = read_testdata(name)
+    comp = O.compress(data, variant)
+    assert Snappy.GetUncompressedLength(comp) == len(data)
+    assert_same(name, Snappy.DecompressToArray(comp), data)
+
+
+@pytest.mark.parametrize("name", ["baddata1.snappy", "baddata2.snappy", "baddata3.snappy"])
+def test_baddata_files(name):                                      # SnappyTests.cs:287-331
+    d = read_testdata(name)
+    with pytest.raises(S.InvalidDataException) as e:
+        Snappy.DecompressToArray(d)
+    assert e.value.status == O.decompress_status(d) == O.ERR_BAD_OFFSET
+    out = np.empty(Snappy.GetUncompressedLength(d), dtype=np.uint8)
+    with pytest.raises(S.InvalidDataException):
+        Snappy.TryDecompress(d, out)
+
+
+def test_decoder_error_taxonomy_matches_oracle():
+    vectors = [
+        b"", bytes([5, 0x00]), bytes([4, 0x0C, 97, 98, 99, 100]), bytes([4, 0x10, 97, 98, 99, 100, 101]),
+        bytes([8, 0x0C, 97, 98, 99, 100, 0x01, 0x00]), bytes([8, 0x0C, 97, 98, 99, 100, 0x01, 0x05]),
+        bytes([8, 0x0C, 97, 98, 99, 100, 0x01, 0x04]), bytes([8, 0x00, 97, 0x1A, 0x01, 0x00]),
+        bytes([6, 0x00, 97, 0x13, 0x01, 0x00, 0x00, 0x00]), bytes([8, 0x0C, 97, 98, 99, 100, 0x02]),
+        bytes([0x80]), bytes([0xFF] * 6), bytes([0xFF, 0xFF, 0xFF, 0xFF, 0x7F, 0]), bytes([0]),
+        bytes([3, 0xFC, 0xFF, 0xFF, 0xFF, 0xFF, 1, 2, 3]),            # 4-byte literal length 2^32: partial literal then stop
+        bytes([70, 0x00, 97]) + bytes([0xFE, 0x01, 0x00]) + bytes([0x12, 0x01, 0x00]),   # 64-byte + 5-byte pattern copies
+    ]
+    N = S._native
+    ctx = S.default_context()
+    for v in vectors:
+        src = np.frombuffer(v, dtype=np.uint8)
+        cap = 128
+        out = np.zeros(cap, dtype=np.uint8)
+        import ctypes as C
+        w = C.c_size_t(0)
+        st = N.lib().snp_try_decompress(ctx.handle, C.c_void_p(src.ctypes.data if src.size else None), src.size,
+                                        C.c_void_p(out.ctypes.data), cap, C.byref(w))
+        ref_out = np.zeros(cap, dtype=np.uint8)
+        rw = C.c_size_t(0)
+        ref = O.lib().orc_decompress(src.ctypes.data if src.size else None, src.size, ref_out.ctypes.data, cap, C.byref(rw))
+        assert st == ref, (v.hex(), st, ref)
+        if ref == 0:
+            assert w.value == rw.value and out[:w.value].tobytes() == ref_out[:rw.value].tobytes(), v.hex()
+
+
+def test_bad_long_length_and_small_buffers():                     # SnappyTests.cs:218-285
+    comp = bytearray(O.compress(b"A" * 1000))
+    comp[0], comp[1] = 255, 127
+    with pytest.raises(S.InvalidDataException):
+        Snappy.DecompressToArray(bytes(comp))
+    comp = O.compress(b"A" * 100000)
+    out = np.empty(100, dtype=np.uint8)
+    with pytest.raises(S.InsufficientBufferException):
+        Snappy.Decompress(comp, out)
+    assert Snappy.TryDecompress(comp, out) == (False, 0)
+    ok, n = Snappy.TryCompress(b"A" * 100000, np.empty(10, dtype=np.uint8))
+    assert (ok, n) == (False, 0)
+    assert Snappy.TryCompress(b"", np.empty(0, dtype=np.uint8)) == (False, 0)          # Snappy.cs:57-62
+    buf = np.zeros(2048, dtype=np.uint8)
+    with pytest.raises(S.InvalidOperationException):                                    # SnappyTests.cs:204-210
+        Snappy.Compress(buf[:1024], buf[1023:])
+
+
+# ------------------------------------------------------------------ compress (bit-exact against the oracle)
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("name", CORPUS)
+def test_compress_corpus_whole_files(name, variant):               # multi-fragment TryCompress  SnappyCompressor.cs:40-80
+    data = read_testdata(name)
+    got = Snappy.CompressToArray(data, ctx_for(variant))
+    assert_same(f"{name}/v{variant}", got, O.compress(data, variant))
+    assert len(got) <= Snappy.GetMaxCompressedLength(len(data))
+
+
+def test_compress_matches_golden_fixtures():
+    html = read_testdata("html")[:65536]
+    for variant, (n, sha) in ((O.HASH_MUL, kats.HTML64K_MUL), (O.HASH_CRC32C, kats.HTML64K_CRC)):
+        c = Snappy.CompressToArray(html, ctx_for(variant))
+        assert len(c) == n and hashlib.sha256(c).hexdigest() == sha
+    g = json.load(open(os.path.join(GOLDEN, "libsnappy_mul_goldens.json")))
+    for name, r in g["whole_files"].items():
+        c = Snappy.CompressToArray(read_testdata(name), ctx_for(O.HASH_MUL))
+        assert len(c) == r["clen"] and hashlib.sha256(c).hexdigest() == r["sha256"], name
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_compress_batch_all_corpus_windows(codec, variant):
+    """Every 64 KiB window of every corpus file in ONE batch launch, ragged last windows included."""
+    parts, offs, lens, pos = [], [], [], 0
+    for name in CORPUS:
+        a, off, ln = blocks_of(read_testdata(name))
+        parts.append(a)
+        offs.append(off + pos)
+        lens.append(ln)
+        pos += a.size
+    data, in_off, in_len = np.concatenate(parts), np.concatenate(offs), np.concatenate(lens)
+    cd = codec[variant]
+    out, out_off, out_len, status = cd.compress(to_dev(data), to_dev(in_off), to_dev(in_len))
+    torch.cuda.synchronize()
+    out, out_off, out_len, status = out.cpu().numpy(), out_off.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy()
+    assert (status == 0).all()
+    for b in range(len(in_len)):
+        ref = O.compress(data[in_off[b]:in_off[b] + in_len[b]].tobytes(), variant)
+        got = out[out_off[b]:out_off[b] + out_len[b]].tobytes()
+        assert_same(f"window {b} v{variant}", got, ref)
+    if variant == O.HASH_MUL:                                       # and against libsnappy 1.1.8's bytes directly
+        g = json.load(open(os.path.join(GOLDEN, "libsnappy_mul_goldens.json")))
+        b = 0
+        for name in CORPUS:
+            nwin = len(blocks_of(read_testdata(name))[1])
+            rows = {r["start"]: r for r in g["files"].get(name, [])}
+            for wdx in range(nwin):
+                r = rows.get(wdx * 65536)
+                if r:
+                    got = out[out_off[b + wdx]:out_off[b + wdx] + out_len[b + wdx]].tobytes()
+                    assert len(got) == r["clen"] and hashlib.sha256(got).hexdigest() == r["sha256"], (name, wdx)
+            b += nwin
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_compress_small_and_edge_lengths(codec, variant):
+    html = read_testdata("html")
+    lens = [0, 1, 2, 3, 14, 15, 16, 17, 30, 31, 32, 33, 48, 63, 64, 65, 127, 128, 255, 256, 257, 511, 512, 513, 1000,
+            4095, 4096, 16383, 16384, 16385, 32768, 65535, 65536]
+    data = np.frombuffer(html, dtype=np.uint8)
+    in_off = np.array([(7 * i) % 1000 for i in range(len(lens))], dtype=np.int64)   # unaligned starts on purpose
+    in_len = np.array(lens, dtype=np.int32)
+    cd = codec[variant]
+    out, out_off, out_len, status = cd.compress(to_dev(data), to_dev(in_off), to_dev(in_len))
+    torch.cuda.synchronize()
+    out, out_off, out_len = out.cpu().numpy(), out_off.cpu().numpy(), out_len.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    for b, n in enumerate(lens):
+        ref = O.compress(html[in_off[b]:in_off[b] + n], variant)
+        assert_same(f"len {n} v{variant}", out[out_off[b]:out_off[b] + out_len[b]].tobytes(), ref)
+
+
+@pytest.mark.parametrize("s", kats.STRING_CASES)
+def test_string_cases(s):                                          # SnappyTests.cs:178-202
+    for variant in VARIANTS:
+        c = Snappy.CompressToArray(s, ctx_for(variant))
+        assert_same("string", c, O.compress(s, variant))
+        assert_same("string rt", Snappy.DecompressToArray(c), s)
+
+
+def test_random_data(codec):                                       # SnappyTests.cs:401-446 (own PRNG; property + parity)
+    rng = np.random.default_rng(301)
+    cases = [datagen.random_data_case(i, rng) for i in list(range(24)) + list(range(100, 1100))]
+    small = [c for c in cases if len(c) <= 65536]
+    big = [c for c in cases if len(c) > 65536]
+    for variant in VARIANTS:
+        cd = codec[variant]
+        data = np.frombuffer(b"".join(small) + b"\0", dtype=np.uint8)
+        in_len = np.array([len(c) for c in small], dtype=np.int32)
+        in_off = np.concatenate([[0], np.cumsum(in_len[:-1], dtype=np.int64)]).astype(np.int64)
+        d_data, d_off, d_len = to_dev(data), to_dev(in_off), to_dev(in_len)
+        out, out_off, out_len, status = cd.compress(d_data, d_off, d_len)
+        back = torch.zeros_like(d_data)
+        dlen, dst = cd.decompress(out, out_off, out_len, back, d_off, d_len)
+        torch.cuda.synchronize()
+        assert (status.cpu().numpy() == 0).all() and (dst.cpu().numpy() == 0).all()
+        assert torch.equal(dlen, d_len) and torch.equal(back[:-1], d_data[:-1])
+        o, oo, ol = out.cpu().numpy(), out_off.cpu().numpy(), out_len.cpu().numpy()
+        for b in range(0, len(small), 7):
+            assert_same(f"random {b}", o[oo[b]:oo[b] + ol[b]].tobytes(), O.compress(small[b], variant))
+        for c in big:
+            comp = Snappy.CompressToArray(c, ctx_for(variant))
+            assert_same("random big", comp, O.compress(c, variant))
+            assert_same("random big rt", Snappy.DecompressToArray(comp), c)
+
+
+# ------------------------------------------------------------------ synthetic configs (BASELINE.json configs 2, 3, 5)
+
+def test_device_generators_match_cpu_statement():
+    html = read_testdata("html")
+    a = SD.html_like_blocks(html, 5, 3, "cuda").cpu().numpy()
+    assert a.tobytes() == datagen.html_like_blocks(html, 5, 3).tobytes()
+    le = SD.low_entropy_blocks(7, 2, "cuda").cpu().numpy()
+    assert le.tobytes() == np.concatenate([datagen.low_entropy_block(7), datagen.low_entropy_block(8)]).tobytes()
+    files = [read_testdata(n) for n in CORPUS]
+    m = SD.corpus_blocks(files, 9, 13, SD.MIXED_SEED, "cuda").cpu().numpy()
+    assert m.tobytes() == datagen.corpus_blocks(files, 9, 13, datagen.MIXED_SEED).tobytes()
+
+
+def _roundtrip_blocks(cd, raw: torch.Tensor, nb: int, variant: int, check_oracle_every: int):
+    in_off, in_len = cd.uniform_layout(nb)
+    out, out_off, out_len, status = cd.compress(raw, in_off, in_len)
+    back = torch.empty_like(raw)
+    dlen, dst = cd.decompress(out, out_off, out_len, back, in_off, in_len)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0
+    assert torch.equal(dlen, in_len)
+    assert torch.equal(back, raw)                                      # encode -> decode is the identity
+    o_len = out_len.cpu().numpy()
+    for b in range(0, nb, check_oracle_every):                         # sampled bit-exact parity with the oracle
+        blk = raw[b * 65536:(b + 1) * 65536].cpu().numpy().tobytes()
+        got = out[b * cd.comp_stride: b * cd.comp_stride + int(o_len[b])].cpu().numpy().tobytes()
+        assert_same(f"block {b} v{variant}", got, O.compress(blk, variant))
+    return o_len
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_config2_html_like_blocks(codec, variant):
+    nb = 2048
+    raw = SD.html_like_blocks(read_testdata("html"), 0, nb, "cuda")
+    o_len = _roundtrip_blocks(codec[variant], raw, nb, variant, 64)
+    assert 0.2 < o_len.sum() / (nb * 65536) < 0.4
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_config3_low_entropy_blocks(codec, variant):               # stresses overlapping / pattern copies
+    nb = 2048
+    raw = SD.low_entropy_blocks(0, nb, "cuda")
+    o_len = _roundtrip_blocks(codec[variant], raw, nb, variant, 64)
+    assert o_len.sum() / (nb * 65536) < 0.2
+
+
+def test_config5_mixed_corpus_blocks(codec):
+    nb = 2048
+    raw = SD.corpus_blocks([read_testdata(n) for n in CORPUS], 0, nb, SD.MIXED_SEED, "cuda")
+    _roundtrip_blocks(codec[O.HASH_CRC32C], raw, nb, O.HASH_CRC32C, 37)
+
+
+def test_zero_and_incompressible_blocks(codec):
+    cd = codec[O.HASH_CRC32C]
+    zeros = torch.zeros(4 * 65536, dtype=torch.uint8, device="cuda")
+    o_len = _roundtrip_blocks(cd, zeros, 4, O.HASH_CRC32C, 1)
+    assert (o_len == 3077).all()                                       # 1 literal + 1024 copies of 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    noise = torch.randint(0, 256, (8 * 65536,), dtype=torch.uint8, device="cuda", generator=g)
+    _roundtrip_blocks(cd, noise, 8, O.HASH_CRC32C, 1)
+
+
+def test_decompress_batch_per_block_status(codec):
+    """Good and bad blocks in one launch: each block reports its own status (SURVEY 8b 'per-block status array')."""
+    cd = codec[O.HASH_CRC32C]
+    good = O.compress(read_testdata("html")[:65536])
+    blobs = [good, read_testdata("baddata1.snappy"), good[:1000], bytes([4, 0x10, 97, 98, 99, 100, 101]), good]
+    caps = [65536, 128082, 65536, 64, 100]
+    data = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    in_len = np.array([len(b) for b in blobs], dtype=np.int32)
+    in_off = np.concatenate([[0], np.cumsum(in_len[:-1])]).astype(np.int64)
+    out_cap = np.array(caps, dtype=np.int32)
+    out_off = np.concatenate([[0], np.cumsum(out_cap[:-1])]).astype(np.int64)
+    out = torch.zeros(int(out_cap.sum()), dtype=torch.uint8, device="cuda")
+    dlen, dst = cd.decompress(to_dev(data), to_dev(in_off), to_dev(in_len), out, to_dev(out_off), to_dev(out_cap))
+    torch.cuda.synchronize()
+    expect = [O.decompress_status(b, c) for b, c in zip(blobs, caps)]
+    assert dst.cpu().tolist() == expect == [0, O.ERR_BAD_OFFSET, O.ERR_INCOMPLETE, O.ERR_TOO_LONG, O.ERR_OUTPUT_TOO_SMALL]
+    assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
+
+
+@pytest.mark.parametrize("fenced", ["0", "1"])
+def test_fenced_and_unfenced_decode_agree(fenced, monkeypatch):
+    """Same-wave store->load ordering: the default kernel relies on in-order vector memory; the fenced variant drains
+    vmcnt before touching young output.  Both must be exact on the overlap-heavy config."""
+    monkeypatch.setenv("SNAPPIER_HIP_FENCED", fenced)
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    nb = 512
+    raw = SD.low_entropy_blocks(1000, nb, "cuda")
+    _roundtrip_blocks(cd, raw, nb, O.HASH_CRC32C, 128)
+
+
+# ------------------------------------------------------------------ CRC-32C
+
+@pytest.mark.parametrize("data,expected", kats.CRC32C)
+def test_crc32c_kats(data, expected):                              # Crc32CAlgorithmTests.cs:7-24
+    assert S.crc32c(data) == expected
+    assert S.crc32c(data, masked=True) == O.crc32c(data, masked=True)
+
+
+def test_crc32c_lengths_and_alignment(codec):
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, 300000, dtype=np.uint8)
+    lens = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 256, 257, 259, 260, 511, 512, 1023, 1024, 1025,
+            4096, 65535, 65536, 65537, 100000]
+    in_off = np.array([(13 * i) % 97 for i in range(len(lens))], dtype=np.int64)
+    in_len = np.array(lens, dtype=np.int32)
+    for masked in (False, True):
+        crc = codec[O.HASH_CRC32C].crc32c(to_dev(data), to_dev(in_off), to_dev(in_len), masked=masked)
+        torch.cuda.synchronize()
+        got = crc.cpu().numpy().view(np.uint32)
+        ref = O.crc32c_batch(data, in_off.astype(np.uint64), in_len.astype(np.uint32), masked)
+        assert got.tolist() == ref.tolist()
+
+
+# ------------------------------------------------------------------ framing (SnappyStream)
+
+def test_frame_encode_reproduces_golden_streams():
+    """hash=MUL: the whole framed stream equals the reference's own html_x_4.snappy / alice29.snappy byte-for-byte."""
+    for name in ("html_x_4.snappy", "alice29.snappy"):
+        stream = read_testdata(name)
+        raw = O.frame_decode(stream)
+        assert_same(name, S.frame_decode(stream), raw)
+        assert_same(name, S.frame_encode(raw, ctx_for(O.HASH_MUL)), stream)
+        assert_same(name, S.frame_encode(raw, ctx_for(O.HASH_CRC32C)), O.frame_encode(raw, O.HASH_CRC32C))
+
+
+@pytest.mark.parametrize("name", CORPUS)
+def test_stream_roundtrip(name):                                   # SnappyStreamTests.cs:8-143
+    import io
+    data = read_testdata(name)
+    sink = io.BytesIO()
+    with S.SnappyStream(sink, S.CompressionMode.Compress, leaveOpen=True) as z:
+        for s in range(0, len(data), 50000):                       # writes that straddle chunk boundaries
+            z.write(data[s:s + 50000])
+    framed = sink.getvalue()
+    assert_same(name, framed, O.frame_encode(data))
+    with S.SnappyStream(io.BytesIO(framed), S.CompressionMode.Decompress) as z:
+        assert_same(name, z.read(), data)
+
+
+def test_framing_uncompressed_block_and_rules():                   # SnappyStreamTests.cs:241-262 + format rules
+    raw = bytes(range(256))
+    s = S.frame_encode(raw)
+    assert len(s) == 10 + 8 + 256 and s[10] == 0x01
+    assert struct.unpack("<I", s[14:18])[0] == O.crc32c(raw, masked=True)
+    assert S.frame_decode(s) == raw
+    assert S.frame_encode(b"") == s[:10] and S.frame_decode(s[:10]) == b""
+    raw = read_testdata("html") + read_testdata("fireworks.jpeg")
+    s = S.frame_encode(raw)
+    assert_same("mixed", s, O.frame_encode(raw))
+    header = s[:10]
+    extra = bytes([0x80, 3, 0, 0, 1, 2, 3]) + bytes([0xFE, 2, 0, 0, 0, 0]) + header
+    assert S.frame_decode(header + extra + s[10:]) == raw
+    for mutate, status in ((lambda b: b[:10] + bytes([0x02, 1, 0, 0, 0]) + b[10:], O.ERR_CHUNK_TYPE),
+                           (lambda b: b[:14] + bytes([b[14] ^ 1]) + b[15:], O.ERR_CRC_MISMATCH),
+                           (lambda b: b[:-5], O.ERR_TRUNCATED_STREAM)):
+        with pytest.raises(S.InvalidDataException) as e:
+            S.frame_decode(mutate(s))
+        assert e.value.status == status
+    # an error in an earlier chunk wins over a later header error, as in the sequential reference
+    bad = bytearray(s + bytes([0x05, 0, 0, 0]))
+    bad[14] ^= 1
+    with pytest.raises(S.InvalidDataException) as e:
+        S.frame_decode(bytes(bad))
+    assert e.value.status == O.ERR_CRC_MISMATCH
+
+
+def test_frame_encode_device_resident(codec):
+    cd = codec[O.HASH_CRC32C]
+    nb = 300
+    raw = SD.html_like_blocks(read_testdata("html"), 0, nb, "cuda")[: nb * 65536 - 12345]   # ragged last chunk
+    framed, written = cd.frame_encode(raw)
+    torch.cuda.synchronize()
+    w = int(written.item())
+    got = framed[:w].cpu().numpy().tobytes()
+    assert_same("device framing", got, O.frame_encode(raw.cpu().numpy().tobytes()))
+    assert_same("device framing rt", S.frame_decode(got), raw.cpu().numpy().tobytes())
+
+
+# ------------------------------------------------------------------ full BASELINE size, size-independent properties
+
+@pytest.mark.timeout(1200)
+def test_full_size_config2_roundtrip(codec):
+    """10 GiB of 64 KiB html-like blocks (BASELINE.json configs[1]): decode(encode(x)) == x for every block, every
+    status OK, every decoded length 65536, and a checksum-of-checksums over the compressed lengths is reproducible."""
+    free, _total = torch.cuda.mem_get_info()
+    nb = 163840
+    need = nb * (65536 * 2 + 76512) + (2 << 30)
+    if free < need:
+        nb = int((free - (2 << 30)) // (65536 * 2 + 76512)) // 1024 * 1024
+    cd = codec[O.HASH_CRC32C]
+    raw = SD.html_like_blocks(read_testdata("html"), 0, nb, "cuda")
+    in_off, in_len = cd.uniform_layout(nb)
+    out, out_off, out_len, status = cd.compress(raw, in_off, in_len)
+    back = torch.empty_like(raw)
+    dlen, dst = cd.decompress(out, out_off, out_len, back, in_off, in_len)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0
+    assert bool((dlen == 65536).all())
+    assert torch.equal(back, raw)
+    # the first 64 blocks are also pinned bit-exactly to the oracle, and block lengths repeat for a second run
+    o_len = out_len.cpu().numpy()
+    for b in range(0, 64, 8):
+        blk = raw[b * 65536:(b + 1) * 65536].cpu().numpy().tobytes()
+        assert out[b * cd.comp_stride: b * cd.comp_stride + int(o_len[b])].cpu().numpy().tobytes() == O.compress(blk)
+    out2, _oo, out_len2, _st = cd.compress(raw, in_off, in_len, out=torch.empty_like(out))
+    torch.cuda.synchronize()
+    assert torch.equal(out_len, out_len2)
