@@ -70,9 +70,13 @@ typedef struct snp_ctx snp_ctx;
 
 /* One context = one HIP device + one stream + reusable HBM scratch.  Snappy.* is re-entrant because it news up
  * a compressor per call (Snappy.cs:64,174,225); the equivalent here is one ctx per calling thread.
- * stream == NULL: the context creates and owns a stream; otherwise it enqueues on the given hipStream_t. */
+ * stream == NULL: the context creates and owns a non-blocking stream; otherwise it enqueues on the given hipStream_t
+ * (see snp_ctx_set_stream to bind the legacy default stream). */
 snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** out_ctx);
 void snp_ctx_destroy(snp_ctx* ctx);
+/* Enqueue all further work of this context on `stream` (a hipStream_t; NULL = the legacy default stream, which is
+ * what torch.cuda.current_stream().cuda_stream is for torch's default stream).  Releases a context-owned stream. */
+snp_status snp_ctx_set_stream(snp_ctx* ctx, void* stream);
 /* Last HIP error string seen by this context ("" if none); pointer valid until the next call on ctx. */
 const char* snp_ctx_last_error(const snp_ctx* ctx);
 /* Block until everything enqueued on the context's stream is done (for the *_batch entry points). */

@@ -39,7 +39,7 @@ def lib() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m snappier_amd.build` "
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python snappier_amd/build.py` "
                           "(there is no CPU fallback for the codec)")
     L = C.CDLL(LIB_PATH)
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
@@ -50,6 +50,7 @@ def lib() -> C.CDLL:
     sig = {
         "snp_ctx_create": (i32, [i32, i32, vp, C.POINTER(vp)]),
         "snp_ctx_destroy": (None, [vp]),
+        "snp_ctx_set_stream": (i32, [vp, vp]),
         "snp_ctx_last_error": (C.c_char_p, [vp]),
         "snp_ctx_synchronize": (i32, [vp]),
         "snp_status_string": (C.c_char_p, [i32]),

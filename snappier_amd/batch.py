@@ -27,6 +27,10 @@ class BlockCodec:
         self.ctx = Context(self.device.index or 0, hash_variant, stream=stream)
         self.comp_stride = (N.lib().snp_max_compressed_length(N.BLOCK_SIZE) + 15) // 16 * 16
 
+    def _bind(self):
+        """Follow torch's current stream, so our launches are ordered with the tensors' producers and consumers."""
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
     # -- layout helpers --------------------------------------------------------------------------------------
     def uniform_layout(self, nblocks: int, block: int = N.BLOCK_SIZE, last_len: int | None = None):
         off = torch.arange(nblocks, dtype=torch.int64, device=self.device) * block
@@ -39,6 +43,7 @@ class BlockCodec:
     def compress(self, data: torch.Tensor, in_off: torch.Tensor, in_len: torch.Tensor, out: torch.Tensor | None = None,
                  out_off: torch.Tensor | None = None):
         """-> (out, out_off, out_len, status).  Block b's output starts at out_off[b] (default stride comp_stride)."""
+        self._bind()
         nb = in_len.numel()
         if out_off is None:
             out_off = torch.arange(nb, dtype=torch.int64, device=self.device) * self.comp_stride
@@ -54,6 +59,7 @@ class BlockCodec:
     def decompress(self, comp: torch.Tensor, in_off: torch.Tensor, in_len: torch.Tensor, out: torch.Tensor,
                    out_off: torch.Tensor, out_cap: torch.Tensor):
         """-> (out_len, status)."""
+        self._bind()
         nb = in_len.numel()
         out_len = torch.empty(nb, dtype=torch.int32, device=self.device)
         status = torch.empty(nb, dtype=torch.int32, device=self.device)
@@ -63,6 +69,7 @@ class BlockCodec:
         return out_len, status
 
     def crc32c(self, data: torch.Tensor, in_off: torch.Tensor, in_len: torch.Tensor, masked: bool = False):
+        self._bind()
         nb = in_len.numel()
         crc = torch.empty(nb, dtype=torch.int32, device=self.device)
         st = N.lib().snp_crc32c_batch(self.ctx.handle, _p(data), _p(in_off), _p(in_len), nb, int(masked), _p(crc))
@@ -72,6 +79,7 @@ class BlockCodec:
     # -- framing, device resident (config 4) --------------------------------------------------------------------
     def frame_encode(self, raw: torch.Tensor):
         """-> (framed tensor (capacity-sized), written: 1-element int64 tensor on device)."""
+        self._bind()
         n = raw.numel()
         cap = N.lib().snp_frame_max_encoded_length(n)
         out = torch.empty(cap, dtype=torch.uint8, device=self.device)
@@ -82,6 +90,7 @@ class BlockCodec:
         return out, written
 
     def frame_decode_chunks(self, framed: torch.Tensor, chunk_type, body_off, body_len, chunk_crc, out, out_off, out_cap):
+        self._bind()
         nc = body_len.numel()
         out_len = torch.empty(nc, dtype=torch.int32, device=self.device)
         status = torch.empty(nc, dtype=torch.int32, device=self.device)

@@ -1,6 +1,6 @@
 """Builds the gfx950 native libraries in-tree with hipcc (cross-compiles without a GPU).
 
-    python -m snappier_amd.build            # libsnappier_hip.so (+ libsnappier_datagen.so, bench/test helper)
+    python snappier_amd/build.py            # libsnappier_hip.so (+ libsnappier_datagen.so, bench/test helper)
 """
 from __future__ import annotations
 

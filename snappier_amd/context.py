@@ -14,15 +14,23 @@ from .errors import InvalidOperationException
 
 class Context:
     def __init__(self, device: int = 0, hash_variant: int = N.HASH_CRC32C, stream: int | None = None):
-        """stream: a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream) or None for a private stream."""
+        """stream: a hipStream_t handle as an int (torch.cuda.current_stream().cuda_stream; 0 = the default stream),
+        or None for a private non-blocking stream owned by the context."""
         self._h = C.c_void_p()
-        st = N.lib().snp_ctx_create(device, hash_variant, C.c_void_p(stream) if stream else None, C.byref(self._h))
+        st = N.lib().snp_ctx_create(device, hash_variant, None, C.byref(self._h))
         if st != N.OK:
             self._h = C.c_void_p()
             raise InvalidOperationException(
                 f"snp_ctx_create(device={device}) failed: {N.status_string(st)} -- the codec runs on a HIP device only")
         self.device = device
         self.hash_variant = hash_variant
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream: int):
+        st = N.lib().snp_ctx_set_stream(self._h, C.c_void_p(stream))
+        if st != N.OK:
+            raise InvalidOperationException(N.status_string(st))
 
     @property
     def handle(self):

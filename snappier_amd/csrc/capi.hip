@@ -105,6 +105,19 @@ void snp_ctx_destroy(snp_ctx* c)
     delete c;
 }
 
+snp_status snp_ctx_set_stream(snp_ctx* c, void* stream)
+{
+    if (!c) return SNP_ERR_BAD_ARG;
+    if (c->own_stream) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+        c->own_stream = false;
+    }
+    c->stream = static_cast<hipStream_t>(stream);
+    return SNP_OK;
+}
+
 const char* snp_ctx_last_error(const snp_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 snp_status snp_ctx_synchronize(snp_ctx* c)

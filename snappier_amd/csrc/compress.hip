@@ -136,7 +136,10 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in
                                                       u32* __restrict__ out_len, i32* __restrict__ status,
                                                       int emit_varint)
 {
-    __shared__ u16 table[16384];                                        // HashTable.cs:17-18
+    __shared__ u16 table_mem[16384];                                    // HashTable.cs:17-18
+    // Lanes communicate through the table (publish / read back), so every access is volatile: the compiler must not
+    // forward a lane's own store to its later load of the same entry -- another lane may have overwritten it.
+    volatile u16* table = table_mem;
     const u32 b = blockIdx.x;
     if (b >= nblocks) return;
     const u32 lane = lane_id();
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in
         // HashTable.CalculateTableSize + Clear  HashTable.cs:52,57-71
         const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << log2_floor(n - 1));
         const u32 mask = 2 * (tsize - 1);                               // :181
-        for (u32 i = lane * 8; i < tsize; i += 64 * 8) *reinterpret_cast<uint4*>(&table[i]) = make_uint4(0, 0, 0, 0);
+        for (u32 i = lane * 8; i < tsize; i += 64 * 8) *reinterpret_cast<uint4*>(&table_mem[i]) = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // order the clear before the volatile traffic below
 
         const u32 limit = n - 15;                                       // :192
         // probe offsets for the first round of a scan, in registers

@@ -22,7 +22,7 @@ def _l():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB):
-            raise ImportError(f"{_LIB} is missing: run `python -m snappier_amd.build`")
+            raise ImportError(f"{_LIB} is missing: run `python snappier_amd/build.py`")
         _lib = C.CDLL(_LIB)
         _lib.snp_gen_corpus_blocks.restype = C.c_int
         _lib.snp_gen_corpus_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32,

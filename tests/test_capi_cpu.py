@@ -13,7 +13,7 @@ from conftest import ROOT, read_testdata
 
 def test_library_built_and_exports_every_declared_symbol():
     from snappier_amd import _native as N
-    assert os.path.exists(N.LIB_PATH), "run python -m snappier_amd.build"
+    assert os.path.exists(N.LIB_PATH), "run python snappier_amd/build.py"
     declared = N.declared_symbols()
     assert len(declared) >= 20 and "snp_compress_batch" in declared and "snp_decompress_batch" in declared
     L = C.CDLL(N.LIB_PATH)
