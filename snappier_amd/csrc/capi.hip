@@ -44,7 +44,7 @@ struct snp_ctx {
     int variant = SNP_HASH_CRC32C;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int fenced = 0;          // SNAPPIER_HIP_FENCED=1: drain vmcnt before reading freshly written output (debug knob)
+    int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
     DevBuf in, out, meta, work;
     std::string err;
 
@@ -88,8 +88,12 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SNP_ERR_DEVICE; }
         c->own_stream = true;
     }
+    // debug knobs: SNAPPIER_HIP_FENCED=1 drains vmcnt before reading young output; SNAPPIER_HIP_DECODE=serial
+    // disables the token-parallel front end of the decompressor (bit 1 of the kernel mode)
     const char* f = getenv("SNAPPIER_HIP_FENCED");
     c->fenced = (f && f[0] == '1') ? 1 : 0;
+    const char* m = getenv("SNAPPIER_HIP_DECODE");
+    if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
     *out_ctx = c;
     return SNP_OK;
 }

@@ -15,6 +15,18 @@
 //     HBM sees the algorithmic bytes only: C read + U written.
 // Vector memory operations of one wave are issued and serviced in order, so a later load observes an earlier store
 // of the same wave (FENCED = true additionally drains vmcnt when a source range is younger than the last drain).
+//
+// BATCHED = true puts a token-parallel front end before that serial loop (the scalar unit -- one instruction per
+// cycle per CU -- is what bounds the serial loop: ~65 SALU instructions per tag):
+//   1. all 64 lanes decode "the tag that would start at input byte ip + lane" (one unaligned 8-byte load each);
+//   2. the true tag starts are picked out by walking next-pointers (1, 2, 3, 4 hops precomputed with ds_bpermute),
+//      four tags per scalar step;
+//   3. a DPP prefix sum of the output lengths gives every tag its output offset;
+//   4. tags execute one per LANE with wide unaligned copies (16/8/4/2/1 B), in dependency rounds: a copy is ready
+//      once its source lies below the watermark of completed output; literals are always ready.  Pattern copies
+//      (offset < length) and literals > 64 B are done cooperatively by the whole wave.
+//   Anything irregular (an error, a tag or literal running past the input, the last < 72 input bytes) leaves the
+//   batch untouched and falls through to the serial loop, which owns the exact error semantics.
 #include "snp_device.h"
 
 namespace {
@@ -55,7 +67,48 @@ __device__ __forceinline__ u64 win_fetch(InWindow& w, u32 v, u32 lane)
     return q >> ((v & 3u) * 8u);            // >= 5 valid bytes
 }
 
-template <bool FENCED>
+// Inclusive prefix sum across the 64 lanes with DPP row shifts / row broadcasts (no LDS, no bpermute).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_or_zero(u32 v)
+{
+    return static_cast<u32>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ u32 wave_inclusive_scan(u32 x)
+{
+    u32 y = x + dpp_or_zero<0x111, 0xf>(x);            // row_shr:1
+    y += dpp_or_zero<0x112, 0xf>(x);                   // row_shr:2
+    y += dpp_or_zero<0x113, 0xf>(x);                   // row_shr:3   -> sums of 4 within a row of 16
+    y += dpp_or_zero<0x114, 0xf>(y);                   // row_shr:4   -> 8
+    y += dpp_or_zero<0x118, 0xf>(y);                   // row_shr:8   -> 16 (whole row)
+    y += dpp_or_zero<0x142, 0xa>(y);                   // row_bcast:15 into rows 1 and 3
+    y += dpp_or_zero<0x143, 0xc>(y);                   // row_bcast:31 into rows 2 and 3
+    return y;
+}
+
+__device__ __forceinline__ u32 bperm(u32 src_lane, u32 v)
+{
+    return static_cast<u32>(__builtin_amdgcn_ds_bpermute(static_cast<int>(src_lane << 2), static_cast<int>(v)));
+}
+
+struct __attribute__((packed)) snp_u16_unaligned { u16 v; };
+
+// One lane copies len (1..64) bytes from s to d, non-overlapping, with exact-length unaligned accesses.
+__device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
+{
+    if (len >= 16) {
+        for (u32 k = 0; k + 16 <= len; k += 16)
+            *reinterpret_cast<snp_u128_unaligned*>(d + k) = *reinterpret_cast<const snp_u128_unaligned*>(s + k);
+        if (len & 15u)                                 // last 16 bytes, overlapping the previous chunk
+            *reinterpret_cast<snp_u128_unaligned*>(d + len - 16) = *reinterpret_cast<const snp_u128_unaligned*>(s + len - 16);
+    } else {
+        if (len & 8u) *reinterpret_cast<snp_u64_unaligned*>(d) = *reinterpret_cast<const snp_u64_unaligned*>(s);
+        if (len & 4u) st32u(d + (len & 8u), ld32u(s + (len & 8u)));
+        if (len & 2u) *reinterpret_cast<snp_u16_unaligned*>(d + (len & 12u)) = *reinterpret_cast<const snp_u16_unaligned*>(s + (len & 12u));
+        if (len & 1u) d[len & 14u] = s[len & 14u];
+    }
+}
+
+template <bool FENCED, bool BATCHED>
 __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                         const u32* __restrict__ in_len, u32 nblocks, u8* out,
                                                         const u64* __restrict__ out_off,
@@ -110,6 +163,114 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
         expected = result;
         if (st == SNP_OK && expected > 0x7fffffffu) st = SNP_ERR_BAD_LENGTH;   // (int)length < 0 in the reference
         if (st == SNP_OK && cap < expected) st = SNP_ERR_OUTPUT_TOO_SMALL;     // Snappy.cs:183-185
+    }
+
+    // ---- token-parallel batches (see the header) ------------------------------------------------------------------
+    if (BATCHED) {
+        while (st == SNP_OK && ip + 72 <= n && op < expected) {
+            // 1. every lane decodes the tag that would start at ip + lane
+            const u64 q = ld64u(src + ip + lane);
+            const u32 c = static_cast<u32>(q) & 0xffu;
+            const u32 type = c & 3u;
+            const u32 hi6 = c >> 2;
+            const u32 b1234 = static_cast<u32>(q >> 8);
+            const u32 extra = type == 0 ? (hi6 >= 60 ? hi6 - 59 : 0) : (type == 3 ? 4 : type);
+            const u32 trailer = extra >= 4 ? b1234 : (b1234 & ((1u << (8 * extra)) - 1u));
+            u32 len, off = 0;
+            if (type == 0) len = hi6 >= 60 ? trailer + 1 : hi6 + 1;    // wraps to 0 for a 2^32-byte literal: caught below
+            else if (type == 1) { len = (hi6 & 7u) + 4; off = ((c >> 5) << 8) | (b1234 & 0xffu); }
+            else { len = hi6 + 1; off = trailer; }
+            const u32 body = lane + 1 + extra;                          // literal body starts at ip + body
+            const u32 n1 = body + (type == 0 ? min(len, 0x40000000u) : 0);   // next tag, relative to ip; always > lane
+            // 2. next-pointers 2, 3 and 4 hops ahead; a value >= 64 leaves the window and then sticks
+            // (the bpermutes run with every lane active: a lane that is masked off reads back as 0 to its readers)
+            const u32 h2 = bperm(n1, n1);
+            const u32 n2 = n1 < 64 ? h2 : n1;
+            const u32 h3 = bperm(n1, n2);
+            const u32 n3 = n1 < 64 ? h3 : n1;
+            const u32 h4 = bperm(n2, n2);
+            const u32 n4 = n2 < 64 ? h4 : n2;
+            u64 tags = 0;
+            u32 pos = 0;
+            do {
+                const u32 a = read_lane(n1, pos), bq = read_lane(n2, pos), cq = read_lane(n3, pos), dq = read_lane(n4, pos);
+                tags |= ballot64(lane == pos || lane == a || lane == bq || lane == cq);
+                pos = dq;
+            } while (pos < 64);
+            const u32 consumed = pos;                                   // input bytes this batch covers
+            const bool real = (tags >> lane) & 1ull;
+            // 3. output offsets
+            const u32 olen = real ? len : 0u;
+            const u32 incl = wave_inclusive_scan(olen);
+            const u32 total = read_lane(incl, 63);
+            const u32 ostart = op + incl - olen;
+            // irregular batches are left to the serial loop (it reports the exact status)
+            const bool bad = real && (type == 0 ? (len == 0 || len > n - ip || body > n - ip - len) : (off == 0 || off > ostart));
+            if (ballot64(bad) != 0ull || total > expected - op || consumed > n - ip) break;
+
+            const bool is_lit = type == 0;
+            u8* const d = dst + ostart;
+            const u8* const s = is_lit ? src + ip + body : dst + (ostart - off);
+            // 4a. literals longer than 64 bytes: whole-wave memcpy each
+            u64 pend = tags;
+            u64 big = ballot64(real && is_lit && len > 64);
+            pend &= ~big;
+            while (big) {
+                const u32 t = static_cast<u32>(__builtin_ctzll(big));
+                big &= big - 1;
+                wave_copy(dst + read_lane(ostart, t), src + ip + read_lane(body, t), read_lane(len, t), lane);
+            }
+            // 4b. dependency rounds
+            const bool simple = is_lit || off >= len;                   // executable by one lane with wide copies
+            const u32 src_end = ostart - off + len;                     // copies: one past the last source byte
+            u32 mark = op;                                              // all output below `mark` is complete
+            for (u32 round = 0;; ++round) {
+                if (round == 3) {
+                    // a long dependency chain inside the batch: finish it tag by tag, whole wave per tag
+                    while (pend) {
+                        const u32 f = static_cast<u32>(__builtin_ctzll(pend));
+                        pend &= pend - 1;
+                        const u32 f_o = read_lane(ostart, f), f_off = read_lane(off, f), f_len = read_lane(len, f);
+                        if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        u32 sidx = lane;
+                        if (f_off < f_len) {
+#pragma unroll
+                            for (int sh = 5; sh >= 0; --sh) {
+                                const u32 t = f_off << sh;
+                                sidx = min(sidx, sidx - t);
+                            }
+                        }
+                        if (lane < f_len) dst[f_o + lane] = dst[f_o - f_off + sidx];
+                    }
+                    break;
+                }
+                if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const bool ready = ((pend >> lane) & 1ull) && simple && (is_lit || src_end <= mark);
+                const u64 rmask = ballot64(ready);
+                if (ready) lane_copy(d, s, len);
+                pend &= ~rmask;
+                if (!pend) break;
+                const u32 f = static_cast<u32>(__builtin_ctzll(pend));  // first tag not yet executed: everything before it is
+                mark = read_lane(ostart, f);
+                const u32 f_off = read_lane(off, f), f_len = read_lane(len, f);
+                if (f_off < f_len) {                                    // pattern copy: cooperative, as in the serial loop
+                    if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    u32 sidx = lane;
+#pragma unroll
+                    for (int sh = 5; sh >= 0; --sh) {
+                        const u32 t = f_off << sh;
+                        sidx = min(sidx, sidx - t);
+                    }
+                    if (lane < f_len) dst[mark + lane] = dst[mark - f_off + sidx];
+                    pend &= ~(1ull << f);
+                    mark += f_len;
+                    if (!pend) break;
+                }
+            }
+            ip += consumed;
+            op += total;
+        }
+        w.wv = 0x80000000u;                                             // force the serial loop to re-seat its window
     }
 
     u32 fenced = 0;   // output bytes below this are known to have left the wave's store queue (FENCED only)
@@ -179,14 +340,19 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
 
 extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                             const u64* out_off, const u32* out_cap, u32* out_len, i32* status,
-                                            const u8* chunk_type, int fenced, hipStream_t stream)
+                                            const u8* chunk_type, int mode, hipStream_t stream)
 {
+    // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end)
     if (nblocks == 0) return hipSuccess;
-    if (fenced)
-        hipLaunchKernelGGL(k_decompress<true>, dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks,
-                           out, out_off, out_cap, out_len, status, chunk_type);
-    else
-        hipLaunchKernelGGL(k_decompress<false>, dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks,
-                           out, out_off, out_cap, out_len, status, chunk_type);
+#define SNP_LAUNCH_DEC(F, B)                                                                                        \
+    hipLaunchKernelGGL((k_decompress<F, B>), dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, \
+                       out, out_off, out_cap, out_len, status, chunk_type)
+    switch (mode & 3) {
+        case 0: SNP_LAUNCH_DEC(false, true); break;
+        case 1: SNP_LAUNCH_DEC(true, true); break;
+        case 2: SNP_LAUNCH_DEC(false, false); break;
+        default: SNP_LAUNCH_DEC(true, false); break;
+    }
+#undef SNP_LAUNCH_DEC
     return hipGetLastError();
 }

@@ -327,15 +327,33 @@ def test_decompress_batch_per_block_status(codec):
     assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
 
 
+@pytest.mark.parametrize("decode", ["batched", "serial"])
 @pytest.mark.parametrize("fenced", ["0", "1"])
-def test_fenced_and_unfenced_decode_agree(fenced, monkeypatch):
+def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     """Same-wave store->load ordering: the default kernel relies on in-order vector memory; the fenced variant drains
-    vmcnt before touching young output.  Both must be exact on the overlap-heavy config."""
+    vmcnt before touching young output.  The token-parallel front end and the serial loop must also agree.  All four
+    kernel variants must be exact on the overlap-heavy config, the html-like config and the mixed corpus."""
     monkeypatch.setenv("SNAPPIER_HIP_FENCED", fenced)
+    monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
     nb = 512
-    raw = SD.low_entropy_blocks(1000, nb, "cuda")
-    _roundtrip_blocks(cd, raw, nb, O.HASH_CRC32C, 128)
+    _roundtrip_blocks(cd, SD.low_entropy_blocks(1000, nb, "cuda"), nb, O.HASH_CRC32C, 128)
+    _roundtrip_blocks(cd, SD.html_like_blocks(read_testdata("html"), 77, nb, "cuda"), nb, O.HASH_CRC32C, 128)
+    _roundtrip_blocks(cd, SD.corpus_blocks([read_testdata(n) for n in CORPUS], 5, nb, SD.MIXED_SEED, "cuda"), nb,
+                      O.HASH_CRC32C, 128)
+    # statuses of broken blocks are identical too
+    blobs = [read_testdata("baddata1.snappy"), O.compress(read_testdata("html")[:65536])[:1000],
+             bytes([4, 0x10, 97, 98, 99, 100, 101]) + bytes(100)]
+    caps = [128082, 65536, 64]
+    data = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    in_len = np.array([len(b) for b in blobs], dtype=np.int32)
+    in_off = np.concatenate([[0], np.cumsum(in_len[:-1])]).astype(np.int64)
+    out_cap = np.array(caps, dtype=np.int32)
+    out_off = np.concatenate([[0], np.cumsum(out_cap[:-1])]).astype(np.int64)
+    out = torch.zeros(int(out_cap.sum()), dtype=torch.uint8, device="cuda")
+    _dlen, dst = cd.decompress(to_dev(data), to_dev(in_off), to_dev(in_len), out, to_dev(out_off), to_dev(out_cap))
+    torch.cuda.synchronize()
+    assert dst.cpu().tolist() == [O.decompress_status(b, c) for b, c in zip(blobs, caps)]
 
 
 # ------------------------------------------------------------------ CRC-32C
