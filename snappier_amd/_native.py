@@ -14,7 +14,7 @@ import re
 import torch  # noqa: F401  (must precede CDLL -- see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsnappier_hip.so")
+LIB_PATH = os.environ.get("SNAPPIER_HIP_LIB") or os.path.join(HERE, "libsnappier_hip.so")   # override: kernel-variant A/B runs
 HEADER_PATH = os.path.join(HERE, "..", "include", "snappier_hip.h")
 
 (OK, ERR_OUTPUT_TOO_SMALL, ERR_BAD_OFFSET, ERR_TOO_LONG, ERR_INCOMPLETE, ERR_BAD_LENGTH, ERR_CRC_MISMATCH,

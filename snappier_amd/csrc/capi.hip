@@ -17,6 +17,9 @@ hipError_t snp_launch_decompress(const u8*, const u64*, const u32*, u32, u8*, co
                                  const u8*, int, hipStream_t);
 hipError_t snp_launch_compress(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int,
                                hipStream_t);
+hipError_t snp_launch_compress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, void*,
+                                     hipStream_t);
+size_t snp_compress_lanes_workspace(u32);
 hipError_t snp_launch_crc32c(const u8*, const u64*, const u32*, u32, int, u32*, const u32*, i32*, hipStream_t);
 hipError_t snp_launch_gather(const u8*, const u64*, const u32*, u8*, const u64*, u32, hipStream_t);
 hipError_t snp_launch_frame_chunks(u64, u32, u64, u64*, u32*, u64*, hipStream_t);
@@ -45,8 +48,22 @@ struct snp_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
-    DevBuf in, out, meta, work;
+    int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= kLanesThreshold), 1 wave-per-fragment, 2 fragment-per-lane
+    DevBuf in, out, meta, work, tables;
     std::string err;
+
+    // One launch of the compressor over nblocks fragments, picking the layout (see compress_lanes.hip).
+    bool launch_compress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
+                         u32* out_len, i32* status, int emit_varint)
+    {
+        const bool lanes = compress_mode == 2 || (compress_mode == 0 && nblocks >= 4096);
+        if (!lanes)
+            return check(snp_launch_compress(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
+                                             emit_varint, stream), "compress launch");
+        if (!ensure(tables, snp_compress_lanes_workspace(nblocks), "hipMalloc(hash tables)")) return false;
+        return check(snp_launch_compress_lanes(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
+                                               emit_varint, tables.p, stream), "compress (lanes) launch");
+    }
 
     bool check(hipError_t e, const char* what)
     {
@@ -94,6 +111,9 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->fenced = (f && f[0] == '1') ? 1 : 0;
     const char* m = getenv("SNAPPIER_HIP_DECODE");
     if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
+    // SNAPPIER_HIP_COMPRESS=wave|lanes pins the compressor layout (default: by batch size)
+    const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
+    c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : 0;
     *out_ctx = c;
     return SNP_OK;
 }
@@ -103,7 +123,7 @@ void snp_ctx_destroy(snp_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work})
+    for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables})
         if (b->p) (void)hipFree(b->p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -203,8 +223,7 @@ snp_status snp_compress_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_
 {
     if (!c || (nblocks && (!in || !in_off || !in_len || !out || !out_off || !out_len || !status))) return SNP_ERR_BAD_ARG;
     if (!c->use_device()) return SNP_ERR_DEVICE;
-    return c->check(snp_launch_compress(in, in_off, in_len, nblocks, out, out_off, out_len, status, c->variant, 1,
-                                        c->stream), "compress launch") ? SNP_OK : SNP_ERR_DEVICE;
+    return c->launch_compress(in, in_off, in_len, nblocks, out, out_off, out_len, status, 1) ? SNP_OK : SNP_ERR_DEVICE;
 }
 
 snp_status snp_decompress_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
@@ -273,8 +292,7 @@ snp_status snp_frame_encode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, 
     const FrameWork w = frame_work_layout(d_work, n);
     bool ok = c->check(snp_launch_frame_chunks(n, nc, kCompStride, w.in_off, w.in_len, w.comp_off, s), "frame chunks");
     // CompressBlock: TryCompress(chunk) = varint + one fragment  (SnappyStreamCompressor.cs:206)
-    ok = ok && c->check(snp_launch_compress(d_in, w.in_off, w.in_len, nc, w.comp, w.comp_off, w.comp_len, w.status,
-                                            c->variant, 1, s), "frame compress");
+    ok = ok && c->launch_compress(d_in, w.in_off, w.in_len, nc, w.comp, w.comp_off, w.comp_len, w.status, 1);
     // masked CRC-32C of the RAW chunk  (:243-245,258-260)
     ok = ok && c->check(snp_launch_crc32c(d_in, w.in_off, w.in_len, nc, 1, w.crc, nullptr, nullptr, s), "frame crc");
     ok = ok && c->check(snp_launch_frame_plan(w.in_len, w.comp_len, nc, w.type, w.payload, w.dst_off, d_written, s),
@@ -345,9 +363,8 @@ snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
 
     bool ok = c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
     ok = ok && c->check(snp_launch_frame_chunks(n, nf, kCompStride, d_in_off, d_in_len, d_comp_off, s), "fragment table");
-    ok = ok && c->check(snp_launch_compress(static_cast<const u8*>(c->in.p), d_in_off, d_in_len, nf,
-                                            static_cast<u8*>(c->work.p), d_comp_off, d_comp_len, d_status, c->variant,
-                                            0, s), "compress");
+    ok = ok && c->launch_compress(static_cast<const u8*>(c->in.p), d_in_off, d_in_len, nf, static_cast<u8*>(c->work.p),
+                                  d_comp_off, d_comp_len, d_status, 0);
     std::vector<u32> comp_len(nf);
     ok = ok && c->check(hipMemcpyAsync(comp_len.data(), d_comp_len, nf * 4ull, hipMemcpyDeviceToHost, s), "D2H lengths");
     ok = ok && c->check(hipStreamSynchronize(s), "sync");

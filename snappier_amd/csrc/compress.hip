@@ -73,6 +73,21 @@ __device__ __forceinline__ u32 table_index(u32 bytes, u32 mask)
 }
 
 __device__ __forceinline__ u32 log2_floor(u32 v) { return 31u - __clz(v); }
+__device__ __forceinline__ void lanes_sync() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ u32 bperm(u32 src_lane, u32 v)
+{
+    return static_cast<u32>(__builtin_amdgcn_ds_bpermute(static_cast<int>(src_lane << 2), static_cast<int>(v)));
+}
+
+// tuning knobs (compile-time; scripts/ablate_compress.sh builds variants to measure each one)
+#ifndef SNP_C_NARROW
+#define SNP_C_NARROW 16
+#endif
+#ifndef SNP_C_SMALLR
+#define SNP_C_SMALLR 0
+#endif
+constexpr u32 kNarrow = SNP_C_NARROW;   // lanes speculated in the first round after a match (most hits are within a few probes)
+constexpr u32 kSmallR = SNP_C_SMALLR;   // up to this many real lanes, bucket conflicts are found by comparing hashes in registers
 
 // EmitLiteral (SnappyCompressor.cs:418-464): tag (+ length bytes) by lane 0, body lane-parallel.  Returns new op.
 __device__ __forceinline__ u32 emit_literal(u8* dst, u32 op, const u8* src, u32 s, u32 len, u32 lane)
@@ -129,6 +144,29 @@ __device__ __forceinline__ u32 emit_copy(u8* dst, u32 op, u32 off, u32 len, u32 
     return op + tl;
 }
 
+// ---- optional phase timing (build with -DSNP_C_PROF=1; scripts/ablate_compress.sh prof) -------------------------
+#ifndef SNP_C_PROF
+#define SNP_C_PROF 0
+#endif
+#if SNP_C_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_DECL u64 prof_t = __builtin_readcyclecounter(); u64 prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_MARK(k)                                                              \
+    do {                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
+        const u64 now_ = __builtin_readcyclecounter();                            \
+        prof_acc[k] += now_ - prof_t;                                             \
+        prof_t = now_;                                                            \
+    } while (0)
+#define PROF_FLUSH                                                                \
+    if (lane == 0)                                                                \
+        for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&g_prof[k_], prof_acc[k_]);
+#else
+#define PROF_DECL
+#define PROF_MARK(k)
+#define PROF_FLUSH
+#endif
+
 template <int VARIANT>
 __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                       const u32* __restrict__ in_len, u32 nblocks,
@@ -136,10 +174,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in
                                                       u32* __restrict__ out_len, i32* __restrict__ status,
                                                       int emit_varint)
 {
-    __shared__ u16 table_mem[16384];                                    // HashTable.cs:17-18
-    // Lanes communicate through the table (publish / read back), so every access is volatile: the compiler must not
-    // forward a lane's own store to its later load of the same entry -- another lane may have overwritten it.
-    volatile u16* table = table_mem;
+    // Lanes communicate through the table (publish / read back).  The compiler must not forward a lane's own store to
+    // its later load of the same entry -- another lane may have overwritten it -- so those hand-offs are separated
+    // by lanes_sync() (a compiler-only memory barrier; DS operations of one wave execute in order anyway).
+    // (Not `volatile`: volatile LDS accesses are left in the generic address space and compile to flat_load/store.)
+    __shared__ u16 table[16384];                                        // HashTable.cs:17-18
     const u32 b = blockIdx.x;
     if (b >= nblocks) return;
     const u32 lane = lane_id();
@@ -164,56 +203,108 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in
         // HashTable.CalculateTableSize + Clear  HashTable.cs:52,57-71
         const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << log2_floor(n - 1));
         const u32 mask = 2 * (tsize - 1);                               // :181
-        for (u32 i = lane * 8; i < tsize; i += 64 * 8) *reinterpret_cast<uint4*>(&table_mem[i]) = make_uint4(0, 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // order the clear before the volatile traffic below
+        for (u32 i = lane * 8; i < tsize; i += 64 * 8) *reinterpret_cast<uint4*>(&table[i]) = make_uint4(0, 0, 0, 0);
+        lanes_sync();
 
         const u32 limit = n - 15;                                       // :192
-        // probe offsets for the first round of a scan, in registers
-        const u32 dA0 = g_probe.d[lane], dA1 = g_probe.d[lane + 1];
-        const u32 dB0 = g_probe.d[lane >= 2 ? lane - 2 : 0], dB1 = g_probe.d[lane >= 2 ? lane - 1 : 1];
+        // Probe offsets for the first round of a scan, in registers.  Computed, not loaded: a value loaded before the
+        // loop makes the compiler re-wait on vmcnt at its first use in every iteration, and because vmcnt retires in
+        // order that wait also drains the previous round's stores.
+        u32 dA0 = 0, dA1 = 0, dB0 = 0, dB1 = 1;
+        {
+            u32 v = 0;
+            for (u32 k = 0; k < 66; ++k) {
+                if (lane == k) dA0 = v;
+                if (lane + 1 == k) dA1 = v;
+                if (lane == k + 2) dB0 = v;
+                if (lane == k + 1 && lane >= 2) dB1 = v;
+                v += 1 + (v >> 5);
+            }
+        }
 
         bool kind_b = false;
         u32 ip = 0, start = 1, kbase = 0;
+        PROF_DECL
+        u32 width = kNarrow;      // lanes speculated this round: kNarrow after a match, 64 once a round found nothing
+        // Input forwarding: the match-extension step of the previous round loaded a dword per lane from consecutive
+        // positions around the end of the match -- exactly where this round probes.  fwd[l] = ld32(src + fwd_base + l).
+        u32 fwd = 0, fwd_base = 0;
+        bool fwd_ok = false;
         for (;;) {
+            // The round state is wave-uniform by construction; say so, or the compiler keeps it in VGPRs and turns
+            // every state update into exec-masked vector code.
+            ip = bcast_first(ip); start = bcast_first(start); kbase = bcast_first(kbase); width = bcast_first(width);
+            op = bcast_first(op); next_emit = bcast_first(next_emit); fwd_base = bcast_first(fwd_base);
+            kind_b = bcast_first(kind_b ? 1u : 0u) != 0;
+            fwd_ok = bcast_first(fwd_ok ? 1u : 0u) != 0;
             // ---- 1. positions, legality ------------------------------------------------------------------
             const bool first_b = kind_b && kbase == 0;
             u32 p, pnext;
-            bool valid, probing;
+            bool legal, probing;
             if (first_b) {
                 p = lane == 0 ? ip - 1 : lane == 1 ? ip : start + dB0;
                 pnext = start + dB1;
-                valid = lane < 2 || pnext <= limit;
+                legal = lane < 2 || pnext <= limit;
                 probing = lane >= 1;
             } else {
                 const u32 d0 = kbase == 0 ? dA0 : g_probe.d[kbase + lane];
                 const u32 d1 = kbase == 0 ? dA1 : g_probe.d[kbase + lane + 1];
                 p = start + d0;
                 pnext = start + d1;
-                valid = pnext <= limit;
+                legal = pnext <= limit;
                 probing = true;
             }
-            const u64 vmask = ballot64(valid);
-            // ---- 2. speculative probe of all lanes against the pre-round table --------------------------------
-            const u32 d = valid ? ld32u(src + p) : 0u;
+            lanes_sync();                                               // table entries may have been rewritten by other lanes
+            const bool spec = lane < width;
+            const bool valid = legal && spec;
+            const u64 wmask = lanes_below(width);
+            const u64 lmask = ballot64(legal);
+            // ---- 2. speculative probe of the lanes against the pre-round table --------------------------------------
+            u32 d;
+            if (first_b && fwd_ok) {
+                // lanes 0..width-1 sit at consecutive positions ip-1, ip, ip+1, ..: a lane shift of the forwarded dwords
+                d = bperm(lane + (ip - 1 - fwd_base), fwd);
+            } else {
+                d = valid ? ld32u(src + p) : 0u;
+            }
+            PROF_MARK(0);                                               // positions + input load
             const u32 h = table_index<VARIANT>(d, mask);
+            PROF_MARK(1);                                               // hash
             const u32 c = table[h];
-            const u32 e = ld32u(src + c);
+            PROF_MARK(2);                                               // table gather (LDS)
+            const u32 e = (valid && probing) ? ld32u(src + c) : ~d;
+            PROF_MARK(3);                                               // candidate gather (global)
             const bool stale = valid && probing && e == d;
             const u64 smask = ballot64(stale);
-            const u64 stop = smask | ~vmask;
-            const u32 first0 = stop ? static_cast<u32>(__builtin_ctzll(stop)) : 64u;
-            const bool terminated = first0 < 64 && !((vmask >> first0) & 1ull);
+            const u64 stop = (smask | ~lmask) & wmask;
+            const u32 first0 = stop ? static_cast<u32>(__builtin_ctzll(stop)) : width;
+            const bool terminated = first0 < width && !((lmask >> first0) & 1ull);
             const bool in_r = valid && (lane < first0 || (lane == first0 && !terminated));
-            // ---- 3. publish + read back: are R's buckets pairwise distinct? -----------------------------------
-            if (in_r) table[h] = static_cast<u16>(p);
-            const u32 rb = table[h];
-            const bool conflict = ballot64(in_r && rb != p) != 0ull;
-            int m = (first0 < 64 && !terminated) ? static_cast<int>(first0) : -1;
+            const u64 rmask = ballot64(in_r);
+            // ---- 3. are R's buckets pairwise distinct?  few lanes: compare hashes in registers; many: publish to
+            //         the table and read back -----------------------------------------------------------------------
+            const bool published = __builtin_popcountll(rmask) > static_cast<int>(kSmallR);
+            bool conflict = false;
+            if (published) {
+                if (in_r) table[h] = static_cast<u16>(p);
+                lanes_sync();
+                const u32 rb = table[h];
+                conflict = ballot64(in_r && rb != p) != 0ull;
+            } else {
+                u64 it = rmask & (rmask - 1);                           // every real lane but the first
+                while (it) {
+                    const u32 j = static_cast<u32>(__builtin_ctzll(it));
+                    it &= it - 1;
+                    if (ballot64(in_r && h == read_lane(h, j)) & lanes_below(j)) { conflict = true; break; }
+                }
+                if (!conflict && in_r) table[h] = static_cast<u16>(p);  // distinct buckets: plain stores
+            }
+            conflict = bcast_first(conflict ? 1u : 0u) != 0;
+            int m = (first0 < width && !terminated) ? static_cast<int>(first0) : -1;
             u32 cand = m >= 0 ? read_lane(c, static_cast<u32>(m)) : 0u;
             if (conflict) {
                 // ---- 4. exact resolution in registers ------------------------------------------------------
                 m = -1;
-                const u64 rmask = ballot64(in_r);
                 u64 it = rmask & ballot64(probing);
                 while (it) {
                     const u32 j = static_cast<u32>(__builtin_ctzll(it));
@@ -229,18 +320,23 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in
                         break;
                     }
                 }
-                // ---- 5. table fix-up: restore, then survivors republish, larger position wins ---------------
-                if (in_r) table[h] = static_cast<u16>(c);
+                // ---- 5. table fix-up: restore what was published, survivors republish, larger position wins ----
+                if (published && in_r) table[h] = static_cast<u16>(c);
                 const bool keep = in_r && (m < 0 || lane <= static_cast<u32>(m));
                 bool active = keep;
+                lanes_sync();
                 while (ballot64(active)) {
                     if (active) table[h] = static_cast<u16>(p);
+                    lanes_sync();
                     active = keep && static_cast<u32>(table[h]) < p;
                 }
             }
+            PROF_MARK(4);                                               // decision, conflict check, table update
+            m = static_cast<int>(bcast_first(static_cast<u32>(m)));
+            cand = bcast_first(cand);
             if (m < 0) {
                 if (terminated) break;                                  // :323-327 -> emit_remainder from next_emit
-                const u32 done = first0 == 64 ? 64u : first0 + 1;       // lanes really processed this round
+                const u32 done = first0 == width ? width : first0 + 1;  // lanes really processed this round
                 if (first_b) {
                     next_emit = ip;                                     // post-copy probe missed: new outer iteration
                     kbase = done > 2 ? done - 2 : 0;
@@ -248,27 +344,66 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in
                 } else {
                     kbase += done;
                 }
+                width = 64;
                 continue;
             }
-            // ---- 6. literal, match extension, copy ------------------------------------------------------------
+            // ---- 6. literal ------------------------------------------------------------------------------------
             const u32 pm = read_lane(p, static_cast<u32>(m));
-            if (pm > next_emit) op = emit_literal(dst, op, src, next_emit, pm - next_emit, lane);   // :347
-            u32 matched = 4;                                            // FindMatchLength  :562-688
-            for (;;) {
-                const u32 pos = pm + matched + lane;
-                const bool same = pos < n && src[cand + matched + lane] == src[pos];
-                const u64 diff = ballot64(!same);
-                if (diff) { matched += static_cast<u32>(__builtin_ctzll(diff)); break; }
-                matched += 64;
+            if (pm > next_emit) {                                       // :347
+                const u32 llen = pm - next_emit;
+                if (first_b && llen < 60) {
+                    // the literal bytes src[ip .. pm) are the low bytes of lanes 1 .. m-1 of this round's probes
+                    if (lane == 0) dst[op] = static_cast<u8>((llen - 1) << 2);
+                    if (lane >= 1 && lane <= llen) dst[op + lane] = static_cast<u8>(d);
+                    op += 1 + llen;
+                } else {
+                    op = emit_literal(dst, op, src, next_emit, llen, lane);
+                }
             }
+            PROF_MARK(5);                                               // literal
+            // ---- 7. match extension (FindMatchLength  :562-688), a dword per lane so the loads can be forwarded --------
+            // Lane l looks at position eb + l; eb starts one byte before the first unknown byte, so lane 0 always
+            // compares a byte already known to match and the first difference is at t >= 1.
+            u32 eb = pm + 3;
+            u32 x;
+            u32 t;
+            for (;;) {
+                const u32 pos = eb + lane;
+                u32 y;
+                if (pos + 4 <= n) {
+                    x = ld32u(src + pos);
+                    y = ld32u(src + (pos - (pm - cand)));
+                } else {                                                // the last three bytes of the fragment
+                    x = 0;
+                    y = 0;
+                    for (u32 k = 0; k < 3; ++k)
+                        if (pos + k < n) {
+                            x |= static_cast<u32>(src[pos + k]) << (8 * k);
+                            y |= static_cast<u32>(src[pos - (pm - cand) + k]) << (8 * k);
+                        }
+                }
+                const bool same = pos < n && ((x ^ y) & 0xffu) == 0;
+                const u64 diff = ballot64(!same);
+                if (diff) { t = static_cast<u32>(__builtin_ctzll(diff)); break; }
+                eb += 63;                                               // lane 63 matched: it becomes the next lane 0
+            }
+            const u32 matched = eb + t - pm;
+            PROF_MARK(6);                                               // match extension
             op = emit_copy(dst, op, pm - cand, matched, lane);          // :371-379
+            PROF_MARK(7);                                               // copy tags
             ip = pm + matched;
             next_emit = ip;
             if (ip >= limit) break;                                     // :381-384
             kind_b = true;
             kbase = 0;
             start = ip + 1;
+            width = kNarrow;
+            // forward the extension dwords to the next round: it needs lanes t-1 .. t-1+width-1 of x
+            fwd = x;
+            fwd_base = eb;
+            fwd_ok = (t - 1 + kNarrow <= 64) && kNarrow <= 34;
         }
+        PROF_FLUSH
     }
     if (next_emit < n) op = emit_literal(dst, op, src, next_emit, n - next_emit, lane);   // emit_remainder  :406-411
 
@@ -279,6 +414,18 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in
 }
 
 }  // namespace
+
+#if SNP_C_PROF
+extern "C" int snp_debug_read_prof(unsigned long long* out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prof), sizeof(g_prof));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+    }
+    return static_cast<int>(e);
+}
+#endif
 
 extern "C" hipError_t snp_launch_compress(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                           const u64* out_off, u32* out_len, i32* status, int variant,

@@ -1,0 +1,198 @@
+// compress_lanes.hip -- Snappy fragment compression, one <= 64 KiB fragment per LANE (gfx950), bit-exact with
+// SnappyCompressor.CompressFragment (Snappier/Internal/SnappyCompressor.cs:174-415) for both TableEntry hashes.
+//
+// Why a second layout.  The reference parse is a serial chain: probe -> table lookup -> candidate compare -> insert,
+// ~4000 dependent steps per html-like fragment.  The wave-per-fragment kernel (compress.hip) keeps the table in LDS,
+// which caps a CU at 5 fragments in flight (5 x 32 KiB = all 160 KiB of LDS); every step is then a chain of
+// dependent memory/LDS round trips with nothing to overlap it, and the kernel measures ~1.5 us per step.
+// For LARGE batches the parallelism that matters is across fragments, so here every lane runs the serial parse of
+// its own fragment: 64 fragments per wavefront, tens of thousands of wavefronts' worth of independent memory
+// streams in flight.  The 16384 x u16 hash table of each fragment lives in an HBM workspace (32 KiB per fragment,
+// zeroed by a memset before the launch -- HashTable.cs:52); LDS holds only the 4 x 256-entry table for the
+// SNP_HASH_CRC32C hash (the CRC step is GF(2)-linear, so it factors over the four input bytes; gfx950 has no
+// CRC instruction).  The kernel is bound by random 64-byte-sector traffic to the tables and candidates, not by
+// instruction issue.  Small batches keep using compress.hip (one wavefront per fragment is better there).
+#include "snp_device.h"
+
+namespace {
+
+constexpr u32 crc_step32(u32 x)
+{
+    for (int k = 0; k < 32; ++k) x = (x >> 1) ^ ((x & 1u) ? 0x82F63B78u : 0u);
+    return x;
+}
+
+struct LaneCtx {
+    const u8* src;
+    u8* dst;
+    u16* table;
+    u32 n;
+    u32 mask;
+    u32 hmask;      // Lmap(mask): H_crc(b) = Lmap(b) ^ Lmap(mask)
+};
+
+template <int VARIANT>
+__device__ __forceinline__ u32 lane_hash(const LaneCtx& c, u32 bytes, const u16 (*lut)[256])
+{
+    u32 hash;
+    if constexpr (VARIANT == SNP_HASH_CRC32C) {
+        // Sse42.Crc32(bytes, mask) = Lmap(bytes ^ mask), Lmap linear: XOR of one table entry per input byte
+        hash = lut[0][bytes & 0xffu] ^ lut[1][(bytes >> 8) & 0xffu] ^ lut[2][(bytes >> 16) & 0xffu] ^ lut[3][bytes >> 24] ^ c.hmask;
+    } else {
+        hash = (0x1e35a7bdu * bytes) >> 17;                            // HashTable.cs:121-122
+    }
+    return (hash & c.mask) >> 1;                                       // :125 (byte offset -> entry index)
+}
+
+// EmitLiteral  SnappyCompressor.cs:418-464
+__device__ __forceinline__ u32 lane_emit_literal(const LaneCtx& c, u32 op, u32 s, u32 len)
+{
+    u8* o = c.dst + op;
+    const u32 k = len - 1;
+    u32 hdr;
+    if (k < 60) { o[0] = static_cast<u8>(k << 2); hdr = 1; }
+    else if (k < 256) { o[0] = static_cast<u8>(60u << 2); o[1] = static_cast<u8>(k); hdr = 2; }
+    else { o[0] = static_cast<u8>(61u << 2); o[1] = static_cast<u8>(k); o[2] = static_cast<u8>(k >> 8); hdr = 3; }   // k < 65536
+    const u8* src = c.src + s;
+    u8* d = o + hdr;
+    u32 i = 0;
+    for (; i + 16 <= len; i += 16)
+        *reinterpret_cast<snp_u128_unaligned*>(d + i) = *reinterpret_cast<const snp_u128_unaligned*>(src + i);
+    for (; i + 4 <= len; i += 4) st32u(d + i, ld32u(src + i));
+    for (; i < len; ++i) d[i] = src[i];
+    return op + hdr + len;
+}
+
+// EmitCopyAtMost64*  SnappyCompressor.cs:467-505
+__device__ __forceinline__ u32 lane_emit_copy64(u8* dst, u32 op, u32 off, u32 len)
+{
+    u8* o = dst + op;
+    if (len < 12 && off < 2048) {
+        o[0] = static_cast<u8>(1u | ((len - 4) << 2) | ((off >> 8) << 5));
+        o[1] = static_cast<u8>(off);
+        return op + 2;
+    }
+    o[0] = static_cast<u8>(2u | ((len - 1) << 2));
+    o[1] = static_cast<u8>(off);
+    o[2] = static_cast<u8>(off >> 8);
+    return op + 3;
+}
+
+// EmitCopyLenLessThan12 / EmitCopyLenGreaterThanOrEqualTo12  SnappyCompressor.cs:507-543
+__device__ __forceinline__ u32 lane_emit_copy(u8* dst, u32 op, u32 off, u32 len)
+{
+    while (len >= 68) { op = lane_emit_copy64(dst, op, off, 64); len -= 64; }
+    if (len > 64) { op = lane_emit_copy64(dst, op, off, 60); len -= 60; }
+    return lane_emit_copy64(dst, op, off, len);
+}
+
+// FindMatchLength  SnappyCompressor.cs:562-688: bytes s1[k] == s2[k] for k < result, s2 + result <= n
+__device__ __forceinline__ u32 lane_find_match_length(const u8* src, u32 s1, u32 s2, u32 n)
+{
+    u32 matched = 0;
+    while (s2 + matched + 8 <= n) {
+        const u64 x = ld64u(src + s1 + matched) ^ ld64u(src + s2 + matched);
+        if (x) return matched + (static_cast<u32>(__builtin_ctzll(x)) >> 3);
+        matched += 8;
+    }
+    while (s2 + matched < n && src[s1 + matched] == src[s2 + matched]) ++matched;
+    return matched;
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                            const u32* __restrict__ in_len, u32 nblocks,
+                                                            u8* __restrict__ out, const u64* __restrict__ out_off,
+                                                            u32* __restrict__ out_len, i32* __restrict__ status,
+                                                            int emit_varint, u16* __restrict__ tables)
+{
+    __shared__ u16 lut[4][256];
+    if (VARIANT == SNP_HASH_CRC32C) {
+        for (u32 e = threadIdx.x; e < 1024; e += SNP_WAVE)
+            lut[e >> 8][e & 255u] = static_cast<u16>(crc_step32((e & 255u) << (8 * (e >> 8))) & 0x7ffeu);
+        __syncthreads();
+    }
+    const u32 b = blockIdx.x * SNP_WAVE + threadIdx.x;
+    if (b >= nblocks) return;
+
+    LaneCtx c;
+    c.src = in + in_off[b];
+    c.dst = out + out_off[b];
+    c.n = in_len[b];
+    c.table = tables + static_cast<size_t>(b) * 16384u;
+    const u32 n = c.n;
+    if (n > SNP_BLOCK_SIZE) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; return; }
+
+    u32 op = 0;
+    if (emit_varint) {                                                 // VarIntEncoding.TryWrite  VarIntEncoding.Write.cs:5-79
+        u32 v = n;
+        while (v >= 128) { c.dst[op++] = static_cast<u8>(v | 0x80u); v >>= 7; }
+        c.dst[op++] = static_cast<u8>(v);
+    }
+
+    u32 ip = 0;
+    if (n >= 15) {                                                     // :190
+        const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << (31u - __clz(n - 1)));   // HashTable.cs:57-71
+        c.mask = 2 * (tsize - 1);                                      // :181
+        c.hmask = static_cast<u16>(crc_step32(c.mask) & 0x7ffeu);
+        const u32 limit = n - 15;                                      // :192
+        for (;;) {
+            const u32 next_emit = ip;                                  // :198
+            ++ip;
+            u32 skip = 32;                                             // :227
+            u32 cand;
+            // scan (:230-341; the unrolled 16-probe section follows the same sequence as the generic loop)
+            for (;;) {
+                const u32 data = ld32u(c.src + ip);
+                const u32 bb = skip >> 5;                              // :319
+                skip += bb;
+                const u32 nxt = ip + bb;
+                if (nxt > limit) { ip = next_emit; goto emit_remainder; }   // :323-327
+                const u32 h = lane_hash<VARIANT>(c, data, lut);
+                cand = c.table[h];                                     // :329
+                c.table[h] = static_cast<u16>(ip);                     // :333
+                if (ld32u(c.src + cand) == data) break;                // :334
+                ip = nxt;
+            }
+            op = lane_emit_literal(c, op, next_emit, ip - next_emit);  // :347
+            for (;;) {                                                 // emit_match  :358-398
+                const u32 base = ip;
+                const u32 matched = 4 + lane_find_match_length(c.src, cand + 4, ip + 4, n);
+                ip += matched;
+                op = lane_emit_copy(c.dst, op, base - cand, matched);  // :371-379
+                if (ip >= limit) goto emit_remainder;                  // :381-384
+                c.table[lane_hash<VARIANT>(c, ld32u(c.src + ip - 1), lut)] = static_cast<u16>(ip - 1);   // :393-394
+                const u32 data = ld32u(c.src + ip);
+                const u32 h = lane_hash<VARIANT>(c, data, lut);
+                cand = c.table[h];                                     // :396
+                c.table[h] = static_cast<u16>(ip);                     // :397
+                if (ld32u(c.src + cand) != data) break;                // :398
+            }
+        }
+    }
+emit_remainder:
+    if (ip < n) op = lane_emit_literal(c, op, ip, n - ip);             // :406-411
+    out_len[b] = op;
+    status[b] = SNP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t snp_compress_lanes_workspace(u32 nblocks) { return static_cast<size_t>(nblocks) * 16384u * sizeof(u16); }
+
+extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
+                                                const u64* out_off, u32* out_len, i32* status, int variant,
+                                                int emit_varint, void* tables, hipStream_t stream)
+{
+    if (nblocks == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(tables, 0, snp_compress_lanes_workspace(nblocks), stream);   // HashTable.cs:52
+    if (e != hipSuccess) return e;
+    const u32 grid = (nblocks + SNP_WAVE - 1) / SNP_WAVE;
+    if (variant == SNP_HASH_CRC32C)
+        hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_CRC32C>, dim3(grid), dim3(SNP_WAVE), 0, stream, in, in_off, in_len,
+                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u16*>(tables));
+    else
+        hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_MUL>, dim3(grid), dim3(SNP_WAVE), 0, stream, in, in_off, in_len,
+                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u16*>(tables));
+    return hipGetLastError();
+}

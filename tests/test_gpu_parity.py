@@ -327,6 +327,35 @@ def test_decompress_batch_per_block_status(codec):
     assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
 
 
+@pytest.mark.parametrize("layout", ["wave", "lanes"])
+def test_compress_layouts_are_bit_identical(layout, monkeypatch):
+    """Both compressor layouts (one fragment per wavefront with the table in LDS; one fragment per lane with the table
+    in an HBM workspace) must give the oracle's bytes on every kind of input, ragged lengths included."""
+    monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout)
+    html = read_testdata("html")
+    for variant in VARIANTS:
+        cd = SB.BlockCodec(0, variant)
+        nb = 300
+        for raw in (SD.html_like_blocks(html, 11, nb, "cuda"), SD.low_entropy_blocks(3, nb, "cuda"),
+                    SD.corpus_blocks([read_testdata(n) for n in CORPUS], 2, nb, SD.MIXED_SEED, "cuda")):
+            _roundtrip_blocks(cd, raw, nb, variant, 23)
+        lens = [0, 1, 14, 15, 16, 17, 31, 32, 33, 255, 256, 257, 1000, 4096, 16383, 16384, 16385, 65535, 65536]
+        data = np.frombuffer(html, dtype=np.uint8)
+        in_off = np.array([(7 * i) % 1000 for i in range(len(lens))], dtype=np.int64)
+        in_len = np.array(lens, dtype=np.int32)
+        out, out_off, out_len, status = cd.compress(to_dev(data), to_dev(in_off), to_dev(in_len))
+        torch.cuda.synchronize()
+        out, out_off, out_len = out.cpu().numpy(), out_off.cpu().numpy(), out_len.cpu().numpy()
+        assert (status.cpu().numpy() == 0).all()
+        for b, n in enumerate(lens):
+            assert_same(f"{layout} len {n} v{variant}", out[out_off[b]:out_off[b] + out_len[b]].tobytes(),
+                        O.compress(html[in_off[b]:in_off[b] + n], variant))
+        # whole files through the host API (multi-fragment)
+        for name in ("html_x_4", "kppkn.gtb", "fireworks.jpeg"):
+            assert_same(f"{layout} {name}", Snappy.CompressToArray(read_testdata(name), S.Context(0, variant)),
+                        O.compress(read_testdata(name), variant))
+
+
 @pytest.mark.parametrize("decode", ["batched", "serial"])
 @pytest.mark.parametrize("fenced", ["0", "1"])
 def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):

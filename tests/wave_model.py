@@ -18,6 +18,8 @@ start + D[k+1] <= limit (:323).
 import numpy as np
 
 W = 64
+NARROW = 16     # lanes speculated in the first round after a match
+SMALL_R = 8     # up to this many real lanes, bucket conflicts are found by comparing hashes in registers
 BLOCK = 65536
 
 
@@ -148,38 +150,45 @@ def compress_fragment_wave(frag: bytes, variant: int, stats=None, rng=None):
     start = 1         # scan start (first probe position)
     kbase = 0
     rounds = slow = 0
+    width = NARROW    # speculation width: NARROW lanes after a match, all 64 once a round found nothing
     while True:
         rounds += 1
         # ---- 1. positions and validity -----------------------------------------------------------------
+        spec = lanes < width
         if kind_b and kbase == 0:
             k = lanes - 2
             p = np.where(lanes == 0, ip - 1, np.where(lanes == 1, ip, start + D[np.maximum(k, 0)]))
-            valid = np.where(lanes < 2, True, start + D[np.maximum(k, 0) + 1] <= limit)
+            legal = np.where(lanes < 2, True, start + D[np.maximum(k, 0) + 1] <= limit)
             probing = lanes >= 1
-            nscan = W - 2
         else:
             k = kbase + lanes
             p = start + D[k]
-            valid = start + D[k + 1] <= limit
+            legal = start + D[k + 1] <= limit
             probing = np.ones(W, dtype=bool)
-            nscan = W
-        # validity is monotone: once a lane is illegal all later ones are
+        valid = legal & spec
+        # legality is monotone: once a lane is illegal all later ones are
         pv = np.where(valid, p, 0)
         d = ld32(buf, pv)
         h = hash_lanes(d, mask, variant)
         c = table[h]                                    # 2. LDS gather of pre-round candidates
         e = ld32(buf, c)                                # 3. candidate bytes
         stale = valid & probing & (e == d)
-        stop = stale | ~valid
-        first0 = int(np.argmax(stop)) if stop.any() else W
-        terminated = first0 < W and not valid[first0]
+        stop = (stale | ~legal) & spec
+        first0 = int(np.argmax(stop)) if stop.any() else width
+        terminated = first0 < width and not legal[first0]
         in_r = (lanes < first0) | ((lanes == first0) & (not terminated))   # lanes whose effects may be real
         in_r &= valid
-        # ---- 4. conflict detection: R publishes p to the table, reads back ---------------------------------
-        _publish(table, h, p, in_r, rng)
-        r = table[h]
-        conflict = bool((in_r & (r != p)).any())
-        m = first0 if (first0 < W and not terminated) else -1
+        # ---- 4. conflict detection -------------------------------------------------------------------------
+        published = int(in_r.sum()) > SMALL_R
+        if published:                                    # large R: publish p to the table, read back
+            _publish(table, h, p, in_r, rng)
+            r = table[h]
+            conflict = bool((in_r & (r != p)).any())
+        else:                                            # small R: pairwise bucket comparison in registers
+            conflict = any(bool((in_r & (h == h[j]) & (lanes < j)).any()) for j in np.nonzero(in_r)[0])
+            if not conflict:
+                _publish(table, h, p, in_r, rng)         # buckets are pairwise distinct: plain stores
+        m = first0 if (first0 < width and not terminated) else -1
         cand = int(c[m]) if m >= 0 else -1
         if conflict:
             slow += 1
@@ -199,8 +208,9 @@ def compress_fragment_wave(frag: bytes, variant: int, stats=None, rng=None):
                     break
             # ---- 6. table fix-up: restore, then lanes <= m (or all of R if no match) republish, max wins ----
             keep = in_r & ((lanes <= m) if m >= 0 else True)
-            for j in np.nonzero(in_r)[0]:
-                table[h[j]] = c[j]
+            if published:
+                for j in np.nonzero(in_r)[0]:
+                    table[h[j]] = c[j]
             active = keep.copy()
             while active.any():
                 _publish(table, h, p, active, rng)
@@ -211,13 +221,14 @@ def compress_fragment_wave(frag: bytes, variant: int, stats=None, rng=None):
             # No match among the lanes processed.  Normally that is all 64; if the slow path *destroyed* the stale
             # hit at first0 (an earlier lane in the same bucket with different bytes is the real candidate), only
             # lanes 0..first0 were processed and the scan resumes right after first0.
-            done = W if first0 == W else first0 + 1
+            done = width if first0 == width else first0 + 1
             if kind_b and kbase == 0:
                 next_emit = ip                           # the post-copy probe missed: new OUTER iteration starts at ip
                 kbase = max(done - 2, 0)
                 kind_b = False
             else:
                 kbase += done
+            width = W
             continue
         # ---- 7. emit literal + copy ------------------------------------------------------------------------
         pm = int(p[m])
@@ -235,6 +246,7 @@ def compress_fragment_wave(frag: bytes, variant: int, stats=None, rng=None):
         if ip >= limit:                                  # :381-384
             break
         kind_b, kbase, start = True, 0, ip + 1
+        width = NARROW
     if next_emit < n:
         emit_literal(out, buf, next_emit, n - next_emit) # :406-411
     if stats is not None:
