@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 V=snappier_amd/variants
-SRC="snappier_amd/csrc/decompress.hip snappier_amd/csrc/compress.hip snappier_amd/csrc/compress_lanes.hip snappier_amd/csrc/crc32c.hip snappier_amd/csrc/framing.hip snappier_amd/csrc/capi.hip"
+SRC="snappier_amd/csrc/decompress.hip snappier_amd/csrc/decompress_lanes.hip snappier_amd/csrc/compress.hip snappier_amd/csrc/compress_lanes.hip snappier_amd/csrc/crc32c.hip snappier_amd/csrc/framing.hip snappier_amd/csrc/capi.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fconstexpr-steps=100000000 -Wno-unused-function -Wl,-rpath,/opt/rocm/lib"
 declare -A VARIANTS=(
   [n16_r0]="-DSNP_C_NARROW=16 -DSNP_C_SMALLR=0"

@@ -17,6 +17,8 @@ hipError_t snp_launch_decompress(const u8*, const u64*, const u32*, u32, u8*, co
                                  const u8*, int, hipStream_t);
 hipError_t snp_launch_compress(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int,
                                hipStream_t);
+hipError_t snp_launch_decompress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*,
+                                       const u8*, hipStream_t);
 hipError_t snp_launch_compress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, void*,
                                      hipStream_t);
 size_t snp_compress_lanes_workspace(u32);
@@ -48,9 +50,22 @@ struct snp_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
+    int decode_layout = 0;   // 0/1 wave-per-block (default), 2 block-per-lane (SNAPPIER_HIP_DECODE=lanes)
     int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= kLanesThreshold), 1 wave-per-fragment, 2 fragment-per-lane
     DevBuf in, out, meta, work, tables;
     std::string err;
+
+    // One launch of the decompressor over nblocks blocks, picking the layout (see decompress_lanes.hip).
+    bool launch_decompress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
+                           const u32* out_cap, u32* out_len, i32* status, const u8* chunk_type)
+    {
+        const bool lanes = decode_layout == 2;   // measured slower than the wave kernel at every batch size: opt-in only
+        if (lanes)
+            return check(snp_launch_decompress_lanes(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
+                                                     chunk_type, stream), "decompress (lanes) launch");
+        return check(snp_launch_decompress(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
+                                           chunk_type, fenced, stream), "decompress launch");
+    }
 
     // One launch of the compressor over nblocks fragments, picking the layout (see compress_lanes.hip).
     bool launch_compress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
@@ -111,6 +126,7 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->fenced = (f && f[0] == '1') ? 1 : 0;
     const char* m = getenv("SNAPPIER_HIP_DECODE");
     if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
+    c->decode_layout = (m && strcmp(m, "lanes") == 0) ? 2 : (m && (strcmp(m, "serial") == 0 || strcmp(m, "batched") == 0)) ? 1 : 0;
     // SNAPPIER_HIP_COMPRESS=wave|lanes pins the compressor layout (default: by batch size)
     const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
     c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : 0;
@@ -233,8 +249,8 @@ snp_status snp_decompress_batch(snp_ctx* c, const uint8_t* in, const uint64_t* i
     if (!c || (nblocks && (!in || !in_off || !in_len || !out || !out_off || !out_cap || !out_len || !status)))
         return SNP_ERR_BAD_ARG;
     if (!c->use_device()) return SNP_ERR_DEVICE;
-    return c->check(snp_launch_decompress(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, nullptr,
-                                          c->fenced, c->stream), "decompress launch") ? SNP_OK : SNP_ERR_DEVICE;
+    return c->launch_decompress(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, nullptr) ? SNP_OK
+                                                                                                              : SNP_ERR_DEVICE;
 }
 
 snp_status snp_crc32c_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
@@ -313,8 +329,7 @@ snp_status snp_frame_decode_chunks_device(snp_ctx* c, const uint8_t* d_in, const
         return SNP_ERR_BAD_ARG;
     if (!c->use_device()) return SNP_ERR_DEVICE;
     hipStream_t s = c->stream;
-    bool ok = c->check(snp_launch_decompress(d_in, body_off, body_len, nchunks, d_out, out_off, out_cap, out_len, status,
-                                             chunk_type, c->fenced, s), "frame decode");
+    bool ok = c->launch_decompress(d_in, body_off, body_len, nchunks, d_out, out_off, out_cap, out_len, status, chunk_type);
     // CRC over the produced bytes, compared with the chunk's stored masked CRC  (SnappyStreamDecompressor.cs:117-131)
     ok = ok && c->check(snp_launch_crc32c(d_out, out_off, out_len, nchunks, 1, nullptr, chunk_crc, status, s),
                         "frame crc verify");

@@ -14,6 +14,10 @@
 // instruction issue.  Small batches keep using compress.hip (one wavefront per fragment is better there).
 #include "snp_device.h"
 
+#ifndef SNP_CL_FLAT
+#define SNP_CL_FLAT 1     // 1: flat per-lane state machine (default); 0: the reference's nested loops, verbatim
+#endif
+
 namespace {
 
 constexpr u32 crc_step32(u32 x)
@@ -131,6 +135,74 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     }
 
     u32 ip = 0;
+#if SNP_CL_FLAT
+    // Flat per-lane state machine: in every trip of the loop each lane does ONE step of its own parse -- a probe
+    // (scan or the probe right after a copy) or a bounded piece of match extension -- so a lane never idles while its
+    // neighbours finish a longer scan.  (With the reference's nested loops a wavefront pays the LONGEST scan of its
+    // 64 fragments on every outer iteration.)
+    enum : u32 { kScan = 0, kPost = 1, kExtend = 2, kDone = 3 };
+    u32 mode = kDone;
+    u32 next_emit = 0, skip = 32, cand = 0, base = 0, mlen = 0, limit = 0;
+    if (n >= 15) {                                                     // :190
+        const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << (31u - __clz(n - 1)));   // HashTable.cs:57-71
+        c.mask = 2 * (tsize - 1);                                      // :181
+        c.hmask = static_cast<u16>(crc_step32(c.mask) & 0x7ffeu);
+        limit = n - 15;                                                // :192
+        mode = kScan;                                                  // first outer iteration: next_emit = 0, ip = 1  :198-199
+        ip = 1;
+    }
+    while (__any(mode != kDone)) {
+        if (mode == kScan || mode == kPost) {
+            bool live = true;
+            u32 nxt = ip;
+            if (mode == kScan) {
+                const u32 bb = skip >> 5;                              // :319
+                skip += bb;
+                nxt = ip + bb;
+                if (nxt > limit) { ip = next_emit; mode = kDone; live = false; }   // :323-327 -> emit_remainder
+            } else {
+                c.table[lane_hash<VARIANT>(c, ld32u(c.src + ip - 1), lut)] = static_cast<u16>(ip - 1);   // :393-394
+            }
+            if (live) {
+                const u32 data = ld32u(c.src + ip);
+                const u32 h = lane_hash<VARIANT>(c, data, lut);
+                cand = c.table[h];                                     // :329 / :396
+                c.table[h] = static_cast<u16>(ip);                     // :333 / :397
+                if (ld32u(c.src + cand) == data) {                     // :334 / :398
+                    if (mode == kScan) op = lane_emit_literal(c, op, next_emit, ip - next_emit);   // :347
+                    base = ip;
+                    mlen = 4;
+                    mode = kExtend;
+                } else if (mode == kScan) {
+                    ip = nxt;                                          // :339-340
+                } else {                                               // the probe after a copy missed: next outer iteration
+                    next_emit = ip;
+                    ++ip;
+                    skip = 32;
+                    mode = kScan;
+                }
+            }
+        }
+        if (mode == kExtend) {                                         // FindMatchLength  :562-688, 32 bytes per trip
+            bool finished = false;
+            for (u32 k = 0; k < 4 && !finished; ++k) {
+                if (base + mlen + 8 <= n) {
+                    const u64 x = ld64u(c.src + cand + mlen) ^ ld64u(c.src + base + mlen);
+                    if (x) { mlen += static_cast<u32>(__builtin_ctzll(x)) >> 3; finished = true; }
+                    else mlen += 8;
+                } else {
+                    while (base + mlen < n && c.src[cand + mlen] == c.src[base + mlen]) ++mlen;
+                    finished = true;
+                }
+            }
+            if (finished) {
+                ip = base + mlen;
+                op = lane_emit_copy(c.dst, op, base - cand, mlen);     // :371-379
+                mode = ip >= limit ? kDone : kPost;                    // :381-384
+            }
+        }
+    }
+#else
     if (n >= 15) {                                                     // :190
         const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << (31u - __clz(n - 1)));   // HashTable.cs:57-71
         c.mask = 2 * (tsize - 1);                                      // :181
@@ -171,6 +243,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
         }
     }
 emit_remainder:
+#endif
     if (ip < n) op = lane_emit_literal(c, op, ip, n - ip);             // :406-411
     out_len[b] = op;
     status[b] = SNP_OK;

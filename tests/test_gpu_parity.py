@@ -356,7 +356,7 @@ def test_compress_layouts_are_bit_identical(layout, monkeypatch):
                         O.compress(read_testdata(name), variant))
 
 
-@pytest.mark.parametrize("decode", ["batched", "serial"])
+@pytest.mark.parametrize("decode", ["batched", "serial", "lanes"])
 @pytest.mark.parametrize("fenced", ["0", "1"])
 def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     """Same-wave store->load ordering: the default kernel relies on in-order vector memory; the fenced variant drains
@@ -372,8 +372,10 @@ def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
                       O.HASH_CRC32C, 128)
     # statuses of broken blocks are identical too
     blobs = [read_testdata("baddata1.snappy"), O.compress(read_testdata("html")[:65536])[:1000],
-             bytes([4, 0x10, 97, 98, 99, 100, 101]) + bytes(100)]
-    caps = [128082, 65536, 64]
+             bytes([4, 0x10, 97, 98, 99, 100, 101]) + bytes(100), bytes([0x80]), bytes([0xFF] * 6), b"",
+             bytes([3, 0xFC, 0xFF, 0xFF, 0xFF, 0xFF, 1, 2, 3]), bytes([8, 0x0C, 97, 98, 99, 100, 0x02]),
+             bytes([70, 0x00, 97]) + bytes([0xFE, 0x01, 0x00]) + bytes([0x12, 0x01, 0x00]), read_testdata("baddata3.snappy")]
+    caps = [128082, 65536, 64, 16, 16, 16, 16, 16, 128, 130378]
     data = np.frombuffer(b"".join(blobs), dtype=np.uint8)
     in_len = np.array([len(b) for b in blobs], dtype=np.int32)
     in_off = np.concatenate([[0], np.cumsum(in_len[:-1])]).astype(np.int64)
