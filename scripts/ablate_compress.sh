@@ -8,11 +8,12 @@ V=snappier_amd/variants
 SRC="snappier_amd/csrc/decompress.hip snappier_amd/csrc/decompress_lanes.hip snappier_amd/csrc/compress.hip snappier_amd/csrc/compress_lanes.hip snappier_amd/csrc/crc32c.hip snappier_amd/csrc/framing.hip snappier_amd/csrc/capi.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fconstexpr-steps=100000000 -Wno-unused-function -Wl,-rpath,/opt/rocm/lib"
 declare -A VARIANTS=(
-  [n16_r0]="-DSNP_C_NARROW=16 -DSNP_C_SMALLR=0"
-  [n16_r8]="-DSNP_C_NARROW=16 -DSNP_C_SMALLR=8"
-  [n8_r0]="-DSNP_C_NARROW=8 -DSNP_C_SMALLR=0"
-  [n32_r0]="-DSNP_C_NARROW=32 -DSNP_C_SMALLR=0"
-  [n16_r4]="-DSNP_C_NARROW=16 -DSNP_C_SMALLR=4"
+  [slots1]="-DSNP_CL_SLOTS=1"
+  [slots2]="-DSNP_CL_SLOTS=2"
+  [slots3]="-DSNP_CL_SLOTS=3"
+  [slots4]="-DSNP_CL_SLOTS=4"
+  [slots6]="-DSNP_CL_SLOTS=6"
+  [slots8]="-DSNP_CL_SLOTS=8"
 )
 if [ "$1" = prof ]; then
   mkdir -p $V
@@ -28,7 +29,7 @@ elif [ "$1" = build ]; then
 else
   mkdir -p gpurun_out
   for k in "${!VARIANTS[@]}"; do
-    r=$(SNAPPIER_HIP_LIB=$PWD/$V/libsnappier_hip_$k.so timeout 120 python bench.py --blocks ${BLOCKS:-32768} --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['compress_GBps'], d['decompress_GBps'])")
+    r=$(SNAPPIER_HIP_LIB=$PWD/$V/libsnappier_hip_$k.so timeout 120 python bench.py --blocks ${BLOCKS:-163840} --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['compress_GBps'], d['decompress_GBps'])")
     echo "$k $r" | tee -a gpurun_out/ablate_compress.log
   done
 fi

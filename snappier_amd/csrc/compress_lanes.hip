@@ -7,7 +7,8 @@
 // dependent memory/LDS round trips with nothing to overlap it, and the kernel measures ~1.5 us per step.
 // For LARGE batches the parallelism that matters is across fragments, so here every lane runs the serial parse of
 // its own fragment: 64 fragments per wavefront, tens of thousands of wavefronts' worth of independent memory
-// streams in flight.  The 16384 x u16 hash table of each fragment lives in an HBM workspace (32 KiB per fragment,
+// streams in flight.  The 16384-entry hash table of each fragment lives in an HBM workspace (u32 entries: position +
+// 16 check bits, 64 KiB per fragment,
 // zeroed by a memset before the launch -- HashTable.cs:52); LDS holds only the 4 x 256-entry table for the
 // SNP_HASH_CRC32C hash (the CRC step is GF(2)-linear, so it factors over the four input bytes; gfx950 has no
 // CRC instruction).  The kernel is bound by random 64-byte-sector traffic to the tables and candidates, not by
@@ -17,8 +18,13 @@
 #ifndef SNP_CL_FLAT
 #define SNP_CL_FLAT 1     // 1: flat per-lane state machine (default); 0: the reference's nested loops, verbatim
 #endif
+#ifndef SNP_CL_SLOTS
+#define SNP_CL_SLOTS 2    // probes of one lane's scan issued together (flat layout only; measured: 2 best, >= 4 costs bandwidth)
+#endif
 
 namespace {
+
+constexpr u32 kSlots = SNP_CL_SLOTS;
 
 constexpr u32 crc_step32(u32 x)
 {
@@ -26,10 +32,17 @@ constexpr u32 crc_step32(u32 x)
     return x;
 }
 
+// Table entry = position (low 16 bits, what the reference stores) | 16 check bits of the 4 bytes at that position.
+// A probe whose check bits differ from the entry's cannot match, so the candidate's bytes (a random 64-byte-sector
+// read) are fetched only when the check bits agree; position 0 (the zero-initialised state) is compared against the
+// fragment's first four bytes kept in a register.  Results are unchanged: "check bits differ" implies "bytes differ".
+__device__ __forceinline__ u32 check_bits(u32 bytes) { return (bytes * 0x9E3779B1u) & 0xffff0000u; }
+
 struct LaneCtx {
     const u8* src;
     u8* dst;
-    u16* table;
+    u32* table;
+    u32 first4;     // ld32(src + 0)
     u32 n;
     u32 mask;
     u32 hmask;      // Lmap(mask): H_crc(b) = Lmap(b) ^ Lmap(mask)
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                                                             const u32* __restrict__ in_len, u32 nblocks,
                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
                                                             u32* __restrict__ out_len, i32* __restrict__ status,
-                                                            int emit_varint, u16* __restrict__ tables)
+                                                            int emit_varint, u32* __restrict__ tables)
 {
     __shared__ u16 lut[4][256];
     if (VARIANT == SNP_HASH_CRC32C) {
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     c.n = in_len[b];
     c.table = tables + static_cast<size_t>(b) * 16384u;
     const u32 n = c.n;
+    c.first4 = n >= 4 ? ld32u(c.src) : 0u;
     if (n > SNP_BLOCK_SIZE) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; return; }
 
     u32 op = 0;
@@ -153,33 +167,84 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     }
     while (__any(mode != kDone)) {
         if (mode == kScan || mode == kPost) {
-            bool live = true;
-            u32 nxt = ip;
-            if (mode == kScan) {
-                const u32 bb = skip >> 5;                              // :319
-                skip += bb;
-                nxt = ip + bb;
-                if (nxt > limit) { ip = next_emit; mode = kDone; live = false; }   // :323-327 -> emit_remainder
-            } else {
-                c.table[lane_hash<VARIANT>(c, ld32u(c.src + ip - 1), lut)] = static_cast<u16>(ip - 1);   // :393-394
+            // A group of up to kSlots consecutive probes of this lane's scan, issued together so that their table and
+            // candidate loads overlap (the serial chain is d -> table[h] -> src[candidate]); the group is then resolved
+            // in order, and only the probes the serial algorithm really reaches commit their table writes.  A probe
+            // right after a copy (kPost) is a group of one, preceded by the insertion of ip-1.
+            const bool post = mode == kPost;
+            u32 p[kSlots], nx[kSlots], sk[kSlots], d[kSlots], h[kSlots], cv[kSlots], e[kSlots];
+            bool legal[kSlots];
+            {
+                u32 q = ip, s = skip;
+                bool ok = true;
+#pragma unroll
+                for (u32 k = 0; k < kSlots; ++k) {
+                    const u32 bb = post ? 0u : s >> 5;                  // :319
+                    s += bb;
+                    p[k] = q;
+                    nx[k] = q + bb;
+                    sk[k] = s;
+                    ok = ok && (post ? k == 0 : nx[k] <= limit);        // :323
+                    legal[k] = ok;
+                    q = nx[k];
+                }
             }
-            if (live) {
-                const u32 data = ld32u(c.src + ip);
-                const u32 h = lane_hash<VARIANT>(c, data, lut);
-                cand = c.table[h];                                     // :329 / :396
-                c.table[h] = static_cast<u16>(ip);                     // :333 / :397
-                if (ld32u(c.src + cand) == data) {                     // :334 / :398
-                    if (mode == kScan) op = lane_emit_literal(c, op, next_emit, ip - next_emit);   // :347
-                    base = ip;
-                    mlen = 4;
-                    mode = kExtend;
-                } else if (mode == kScan) {
-                    ip = nxt;                                          // :339-340
-                } else {                                               // the probe after a copy missed: next outer iteration
+            if (post) {                                                 // :393-394
+                const u32 dm1 = ld32u(c.src + ip - 1);
+                c.table[lane_hash<VARIANT>(c, dm1, lut)] = (ip - 1) | check_bits(dm1);
+            }
+#pragma unroll
+            for (u32 k = 0; k < kSlots; ++k) d[k] = legal[k] ? ld32u(c.src + p[k]) : 0u;
+#pragma unroll
+            for (u32 k = 0; k < kSlots; ++k) h[k] = lane_hash<VARIANT>(c, d[k], lut);
+#pragma unroll
+            for (u32 k = 0; k < kSlots; ++k) cv[k] = legal[k] ? c.table[h[k]] : 0u;   // :329 / :396  (position | check bits)
+            // a later probe of the group falling into the bucket of an earlier one sees that probe's entry
+#pragma unroll
+            for (u32 k = 1; k < kSlots; ++k)
+#pragma unroll
+                for (u32 i = 0; i < k; ++i)
+                    if (legal[k] && h[i] == h[k]) cv[k] = p[i] | check_bits(d[i]);
+#pragma unroll
+            for (u32 k = 0; k < kSlots; ++k) {
+                const u32 pos = cv[k] & 0xffffu;
+                e[k] = ~d[k];
+                if (legal[k]) {
+                    if (pos == 0) e[k] = c.first4;
+                    else if ((cv[k] & 0xffff0000u) == check_bits(d[k])) e[k] = ld32u(c.src + pos);
+                }
+                cv[k] = pos;
+            }
+            // in-order resolution
+            bool hit = false, ended = false;
+#pragma unroll
+            for (u32 k = 0; k < kSlots; ++k) {
+                if (!hit && !ended) {
+                    if (!legal[k]) {
+                        ended = true;
+                        if (!post) { ip = next_emit; mode = kDone; }    // :323-327 -> emit_remainder
+                    } else {
+                        c.table[h[k]] = p[k] | check_bits(d[k]);        // :333 / :397
+                        if (e[k] == d[k]) {                             // :334 / :398
+                            hit = true;
+                            if (!post) op = lane_emit_literal(c, op, next_emit, p[k] - next_emit);   // :347
+                            base = p[k];
+                            cand = cv[k];
+                            mlen = 4;
+                            mode = kExtend;
+                        }
+                    }
+                }
+            }
+            if (!hit && mode != kDone) {
+                if (post) {                                             // the probe after a copy missed: next outer iteration
                     next_emit = ip;
                     ++ip;
                     skip = 32;
                     mode = kScan;
+                } else {                                                // all kSlots probes missed  :339-340
+                    ip = nx[kSlots - 1];
+                    skip = sk[kSlots - 1];
                 }
             }
         }
@@ -221,8 +286,8 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 const u32 nxt = ip + bb;
                 if (nxt > limit) { ip = next_emit; goto emit_remainder; }   // :323-327
                 const u32 h = lane_hash<VARIANT>(c, data, lut);
-                cand = c.table[h];                                     // :329
-                c.table[h] = static_cast<u16>(ip);                     // :333
+                cand = c.table[h] & 0xffffu;                           // :329
+                c.table[h] = ip | check_bits(data);                    // :333
                 if (ld32u(c.src + cand) == data) break;                // :334
                 ip = nxt;
             }
@@ -233,11 +298,12 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 ip += matched;
                 op = lane_emit_copy(c.dst, op, base - cand, matched);  // :371-379
                 if (ip >= limit) goto emit_remainder;                  // :381-384
-                c.table[lane_hash<VARIANT>(c, ld32u(c.src + ip - 1), lut)] = static_cast<u16>(ip - 1);   // :393-394
+                const u32 dm1 = ld32u(c.src + ip - 1);
+                c.table[lane_hash<VARIANT>(c, dm1, lut)] = (ip - 1) | check_bits(dm1);   // :393-394
                 const u32 data = ld32u(c.src + ip);
                 const u32 h = lane_hash<VARIANT>(c, data, lut);
-                cand = c.table[h];                                     // :396
-                c.table[h] = static_cast<u16>(ip);                     // :397
+                cand = c.table[h] & 0xffffu;                           // :396
+                c.table[h] = ip | check_bits(data);                    // :397
                 if (ld32u(c.src + cand) != data) break;                // :398
             }
         }
@@ -251,7 +317,7 @@ emit_remainder:
 
 }  // namespace
 
-extern "C" size_t snp_compress_lanes_workspace(u32 nblocks) { return static_cast<size_t>(nblocks) * 16384u * sizeof(u16); }
+extern "C" size_t snp_compress_lanes_workspace(u32 nblocks) { return static_cast<size_t>(nblocks) * 16384u * sizeof(u32); }
 
 extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                                 const u64* out_off, u32* out_len, i32* status, int variant,
@@ -263,9 +329,9 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const u32 grid = (nblocks + SNP_WAVE - 1) / SNP_WAVE;
     if (variant == SNP_HASH_CRC32C)
         hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_CRC32C>, dim3(grid), dim3(SNP_WAVE), 0, stream, in, in_off, in_len,
-                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u16*>(tables));
+                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables));
     else
         hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_MUL>, dim3(grid), dim3(SNP_WAVE), 0, stream, in, in_off, in_len,
-                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u16*>(tables));
+                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables));
     return hipGetLastError();
 }
