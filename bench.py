@@ -90,8 +90,10 @@ def main():
         sys.exit("bench.py needs an MI355X: the codec has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or "RANK" in os.environ             # under torch.distributed.run: always take the RCCL path
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
 
     import snappier_amd as S
@@ -125,7 +127,7 @@ def main():
         e1.record()
         dlen, dst = cd.decompress(comp, comp_off, out_len, back, in_off, in_len)
         e2.record()
-        if world > 1:                                       # the one exchange step: (length, status) directory
+        if distributed:                                     # the one exchange step: (length, status) directory
             sharding.gather_directory(out_len, status, nb * world)
         if record:
             t_comp.append((e0, e1))
@@ -137,7 +139,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +149,7 @@ def main():
         out_len, status, dlen, dst = step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -193,7 +195,7 @@ def main():
             ns = min(args.cpu_sample_blocks, nb)
             line["cpu_baseline"] = cpu_baseline(raw[: ns * BLOCK].cpu().numpy(), variant)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -33,6 +33,7 @@ hipError_t snp_launch_frame_emit(const u8*, const u64*, const u8*, const u64*, c
 
 namespace {
 
+constexpr int kDefaultDecLds = 0;
 constexpr u64 kCompStride = 76496 + 16;   // snp_max_compressed_length(65536), padded to a 16-byte multiple
 
 struct DevBuf {
@@ -50,6 +51,7 @@ struct snp_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
+    int dec_lds = 0;         // dynamic LDS bytes per decode wavefront (occupancy throttle)
     int decode_layout = 0;   // 0/1 wave-per-block (default), 2 block-per-lane (SNAPPIER_HIP_DECODE=lanes)
     int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= kLanesThreshold), 1 wave-per-fragment, 2 fragment-per-lane
     DevBuf in, out, meta, work, tables;
@@ -64,7 +66,7 @@ struct snp_ctx {
             return check(snp_launch_decompress_lanes(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
                                                      chunk_type, stream), "decompress (lanes) launch");
         return check(snp_launch_decompress(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
-                                           chunk_type, fenced, stream), "decompress launch");
+                                           chunk_type, fenced | ((dec_lds / 256) << 8), stream), "decompress launch");
     }
 
     // One launch of the compressor over nblocks fragments, picking the layout (see compress_lanes.hip).
@@ -127,6 +129,9 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     const char* m = getenv("SNAPPIER_HIP_DECODE");
     if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
     c->decode_layout = (m && strcmp(m, "lanes") == 0) ? 2 : (m && (strcmp(m, "serial") == 0 || strcmp(m, "batched") == 0)) ? 1 : 0;
+    // SNAPPIER_HIP_DEC_LDS=<bytes>: dynamic LDS per decode wavefront, an occupancy throttle (160 KiB / bytes blocks per CU)
+    const char* dl = getenv("SNAPPIER_HIP_DEC_LDS");
+    c->dec_lds = dl ? (atoi(dl) / 256) * 256 : kDefaultDecLds;
     // SNAPPIER_HIP_COMPRESS=wave|lanes pins the compressor layout (default: by batch size)
     const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
     c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : 0;

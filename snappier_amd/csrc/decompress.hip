@@ -167,9 +167,12 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
 
     // ---- token-parallel batches (see the header) ------------------------------------------------------------------
     if (BATCHED) {
+        // the next batch's input window is requested as soon as this batch's length is known, so its latency overlaps
+        // this batch's copies
+        u64 q_next = (st == SNP_OK && ip + 72 <= n) ? ld64u(src + ip + lane) : 0ull;
         while (st == SNP_OK && ip + 72 <= n && op < expected) {
             // 1. every lane decodes the tag that would start at ip + lane
-            const u64 q = ld64u(src + ip + lane);
+            const u64 q = q_next;
             const u32 c = static_cast<u32>(q) & 0xffu;
             const u32 type = c & 3u;
             const u32 hi6 = c >> 2;
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                 pos = dq;
             } while (pos < 64);
             const u32 consumed = pos;                                   // input bytes this batch covers
+            if (consumed <= n - ip && ip + consumed + 72 <= n) q_next = ld64u(src + ip + consumed + lane);
             const bool real = (tags >> lane) & 1ull;
             // 3. output offsets
             const u32 olen = real ? len : 0u;
@@ -342,11 +346,13 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
                                             const u64* out_off, const u32* out_cap, u32* out_len, i32* status,
                                             const u8* chunk_type, int mode, hipStream_t stream)
 {
-    // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end)
+    // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end); bits 8..: dynamic LDS bytes / 256 requested
+    // per wavefront purely to cap how many blocks a CU decodes at once (keeps their outputs cache resident)
     if (nblocks == 0) return hipSuccess;
+    const unsigned lds_bytes = static_cast<unsigned>(mode >> 8) * 256u;
 #define SNP_LAUNCH_DEC(F, B)                                                                                        \
-    hipLaunchKernelGGL((k_decompress<F, B>), dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, \
-                       out, out_off, out_cap, out_len, status, chunk_type)
+    hipLaunchKernelGGL((k_decompress<F, B>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,   \
+                       nblocks, out, out_off, out_cap, out_len, status, chunk_type)
     switch (mode & 3) {
         case 0: SNP_LAUNCH_DEC(false, true); break;
         case 1: SNP_LAUNCH_DEC(true, true); break;
