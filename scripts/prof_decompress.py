@@ -1,0 +1,25 @@
+"""Event counts of the token-parallel decompressor (needs a libsnappier_hip built with -DSNP_D_PROF=1)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import snappier_amd as S
+from snappier_amd import batch as SB, datagen as SD
+nb = int(os.environ.get("BLOCKS", "4096"))
+kind = os.environ.get("DATA", "html")
+html = open("tests/golden/testdata/html", "rb").read()
+cd = SB.BlockCodec(0, S.HASH_CRC32C)
+raw = SD.html_like_blocks(html, 0, nb, "cuda") if kind == "html" else SD.low_entropy_blocks(0, nb, "cuda")
+in_off, in_len = cd.uniform_layout(nb)
+out, out_off, out_len, st = cd.compress(raw, in_off, in_len)
+back = torch.empty_like(raw)
+L = S.lib()
+buf = (C.c_ulonglong * 16)()
+L.snp_debug_read_dprof(buf, 1)
+cd.decompress(out, out_off, out_len, back, in_off, in_len)
+torch.cuda.synchronize()
+L.snp_debug_read_dprof(buf, 1)
+names = ["batches", "tags in batches", "output bytes in batches", "rounds", "tags finished one by one", "tags round0",
+         "tags round1", "tags round2", "pattern copies (coop)", "tags in serial loop"]
+for k, nme in enumerate(names):
+    print(f"{nme:28s} {buf[k]/nb:12.1f} per block")
+print("rounds per batch", buf[3] / max(buf[0], 1), " tags per batch", buf[1] / max(buf[0], 1))

@@ -92,21 +92,44 @@ __device__ __forceinline__ u32 bperm(u32 src_lane, u32 v)
 
 struct __attribute__((packed)) snp_u16_unaligned { u16 v; };
 
-// One lane copies len (1..64) bytes from s to d, non-overlapping, with exact-length unaligned accesses.
+// One lane copies len (1..64) bytes from s to d (non-overlapping).  Stores are exact; LOADS are not: every lane reads
+// 16 bytes at s (and, above 16, the 16 bytes ending exactly at len), so one memory round trip serves every size class
+// and the 8/4/2/1-byte stores of a short copy are cut out of the registers.  The caller guarantees that reading up to 15
+// bytes past the source is safe.  Copies longer than 32 bytes take one or two extra 16-byte pieces in the middle.
 __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
 {
+    const snp_u128_unaligned p0 = *reinterpret_cast<const snp_u128_unaligned*>(s);
     if (len >= 16) {
-        for (u32 k = 0; k + 16 <= len; k += 16)
-            *reinterpret_cast<snp_u128_unaligned*>(d + k) = *reinterpret_cast<const snp_u128_unaligned*>(s + k);
-        if (len & 15u)                                 // last 16 bytes, overlapping the previous chunk
-            *reinterpret_cast<snp_u128_unaligned*>(d + len - 16) = *reinterpret_cast<const snp_u128_unaligned*>(s + len - 16);
+        snp_u128_unaligned p1 = p0;
+        if (len > 16) p1 = *reinterpret_cast<const snp_u128_unaligned*>(s + len - 16);
+        *reinterpret_cast<snp_u128_unaligned*>(d) = p0;
+        if (len > 16) *reinterpret_cast<snp_u128_unaligned*>(d + len - 16) = p1;
+        if (len > 32) {
+            *reinterpret_cast<snp_u128_unaligned*>(d + 16) = *reinterpret_cast<const snp_u128_unaligned*>(s + 16);
+            if (len > 48) *reinterpret_cast<snp_u128_unaligned*>(d + 32) = *reinterpret_cast<const snp_u128_unaligned*>(s + 32);
+        }
     } else {
-        if (len & 8u) *reinterpret_cast<snp_u64_unaligned*>(d) = *reinterpret_cast<const snp_u64_unaligned*>(s);
-        if (len & 4u) st32u(d + (len & 8u), ld32u(s + (len & 8u)));
-        if (len & 2u) *reinterpret_cast<snp_u16_unaligned*>(d + (len & 12u)) = *reinterpret_cast<const snp_u16_unaligned*>(s + (len & 12u));
-        if (len & 1u) d[len & 14u] = s[len & 14u];
+        const u32 o4 = len & 8u, o2 = len & 12u, o1 = len & 14u;
+        const u32 w4 = o4 ? p0.v[2] : p0.v[0];
+        const u32 w2 = (o2 & 8u) ? ((o2 & 4u) ? p0.v[3] : p0.v[2]) : ((o2 & 4u) ? p0.v[1] : p0.v[0]);
+        const u32 w1 = ((o1 & 8u) ? ((o1 & 4u) ? p0.v[3] : p0.v[2]) : ((o1 & 4u) ? p0.v[1] : p0.v[0])) >> ((o1 & 2u) * 8u);
+        if (len & 8u) reinterpret_cast<snp_u64_unaligned*>(d)->v = p0.v[0] | (static_cast<u64>(p0.v[1]) << 32);
+        if (len & 4u) st32u(d + o4, w4);
+        if (len & 2u) reinterpret_cast<snp_u16_unaligned*>(d + o2)->v = static_cast<u16>(w2);
+        if (len & 1u) d[o1] = static_cast<u8>(w1);
     }
 }
+
+// ---- optional event counters (build with -DSNP_D_PROF=1; scripts/prof_decompress.py) --------------------------------
+#ifndef SNP_D_PROF
+#define SNP_D_PROF 0
+#endif
+#if SNP_D_PROF
+__device__ unsigned long long g_dprof[16];
+#define DPROF_ADD(k, v) do { if (lane == 0) atomicAdd(&g_dprof[k], static_cast<unsigned long long>(v)); } while (0)
+#else
+#define DPROF_ADD(k, v)
+#endif
 
 template <bool FENCED, bool BATCHED>
 __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ in, const u64* __restrict__ in_off,
@@ -209,9 +232,14 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
             const u32 total = read_lane(incl, 63);
             const u32 ostart = op + incl - olen;
             // irregular batches are left to the serial loop (it reports the exact status)
-            const bool bad = real && (type == 0 ? (len == 0 || len > n - ip || body > n - ip - len) : (off == 0 || off > ostart));
-            if (ballot64(bad) != 0ull || total > expected - op || consumed > n - ip) break;
+            // (+16: lane_copy may read up to 15 bytes past a literal's body / a copy's source)
+            const bool bad = real && (type == 0 ? (len == 0 || len + 16 > n - ip || body > n - ip - len - 16)
+                                                : (off == 0 || off > ostart));
+            if (ballot64(bad) != 0ull || total + 16 > expected - op || consumed > n - ip) break;
 
+            DPROF_ADD(0, 1);                                            // batches
+            DPROF_ADD(1, __builtin_popcountll(tags));                   // tags in batches
+            DPROF_ADD(2, total);                                        // output bytes of batches
             const bool is_lit = type == 0;
             u8* const d = dst + ostart;
             const u8* const s = is_lit ? src + ip + body : dst + (ostart - off);
@@ -229,7 +257,9 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
             const u32 src_end = ostart - off + len;                     // copies: one past the last source byte
             u32 mark = op;                                              // all output below `mark` is complete
             for (u32 round = 0;; ++round) {
+                DPROF_ADD(3, 1);                                        // rounds (incl. the finishing pass)
                 if (round == 3) {
+                    DPROF_ADD(4, __builtin_popcountll(pend));           // tags finished one by one
                     // a long dependency chain inside the batch: finish it tag by tag, whole wave per tag
                     while (pend) {
                         const u32 f = static_cast<u32>(__builtin_ctzll(pend));
@@ -251,6 +281,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                 if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const bool ready = ((pend >> lane) & 1ull) && simple && (is_lit || src_end <= mark);
                 const u64 rmask = ballot64(ready);
+                DPROF_ADD(5 + (round < 3 ? round : 2), __builtin_popcountll(rmask));   // tags executed in round 0 / 1 / 2
                 if (ready) lane_copy(d, s, len);
                 pend &= ~rmask;
                 if (!pend) break;
@@ -258,6 +289,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                 mark = read_lane(ostart, f);
                 const u32 f_off = read_lane(off, f), f_len = read_lane(len, f);
                 if (f_off < f_len) {                                    // pattern copy: cooperative, as in the serial loop
+                    DPROF_ADD(8, 1);                                    // pattern copies done by the whole wave
                     if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     u32 sidx = lane;
 #pragma unroll
@@ -281,6 +313,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
 
     // ---- tag loop  (SnappyDecompressor.cs:234-341) -----------------------------------------------------------
     while (st == SNP_OK && ip < n) {
+        DPROF_ADD(9, 1);                                                // tags taken by the serial loop
         const u64 q = win_fetch(w, ip + mis, lane);
         const u32 c = static_cast<u32>(q) & 0xffu;
         const u32 type = c & 3u;
@@ -341,6 +374,18 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
 }
 
 }  // namespace
+
+#if SNP_D_PROF
+extern "C" int snp_debug_read_dprof(unsigned long long* out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dprof), sizeof(g_dprof));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_dprof), z, sizeof(z));
+    }
+    return static_cast<int>(e);
+}
+#endif
 
 extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                             const u64* out_off, const u32* out_cap, u32* out_len, i32* status,
