@@ -126,9 +126,21 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
 #endif
 #if SNP_D_PROF
 __device__ unsigned long long g_dprof[16];
-#define DPROF_ADD(k, v) do { if (lane == 0) atomicAdd(&g_dprof[k], static_cast<unsigned long long>(v)); } while (0)
+#define DPROF_ADD(k, v) do { if (lane == 0 && ((k) >= 10 || SNP_D_PROF == 2)) atomicAdd(&g_dprof[k], static_cast<unsigned long long>(v)); } while (0)
+#define DPROF_T0 u64 dprof_t = __builtin_readcyclecounter(); u64 dprof_acc[5] = {0, 0, 0, 0, 0};
+#define DPROF_TIME(k)                                                             \
+    do {                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
+        const u64 now_ = __builtin_readcyclecounter();                            \
+        dprof_acc[(k) - 10] += now_ - dprof_t;                                    \
+        dprof_t = now_;                                                           \
+    } while (0)
+#define DPROF_FLUSH do { for (int k_ = 0; k_ < 5; ++k_) DPROF_ADD(10 + k_, dprof_acc[k_]); } while (0)
 #else
 #define DPROF_ADD(k, v)
+#define DPROF_T0
+#define DPROF_TIME(k)
+#define DPROF_FLUSH
 #endif
 
 template <bool FENCED, bool BATCHED>
@@ -193,9 +205,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
         // the next batch's input window is requested as soon as this batch's length is known, so its latency overlaps
         // this batch's copies
         u64 q_next = (st == SNP_OK && ip + 72 <= n) ? ld64u(src + ip + lane) : 0ull;
+        DPROF_T0
         while (st == SNP_OK && ip + 72 <= n && op < expected) {
             // 1. every lane decodes the tag that would start at ip + lane
             const u64 q = q_next;
+            DPROF_TIME(10);                                             // wait for the input window
             const u32 c = static_cast<u32>(q) & 0xffu;
             const u32 type = c & 3u;
             const u32 hi6 = c >> 2;
@@ -216,6 +230,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
             const u32 n3 = n1 < 64 ? h3 : n1;
             const u32 h4 = bperm(n2, n2);
             const u32 n4 = n2 < 64 ? h4 : n2;
+            DPROF_TIME(11);                                             // tag decode + next-pointers
             u64 tags = 0;
             u32 pos = 0;
             do {
@@ -224,6 +239,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                 pos = dq;
             } while (pos < 64);
             const u32 consumed = pos;                                   // input bytes this batch covers
+            DPROF_TIME(12);                                             // chain walk
             if (consumed <= n - ip && ip + consumed + 72 <= n) q_next = ld64u(src + ip + consumed + lane);
             const bool real = (tags >> lane) & 1ull;
             // 3. output offsets
@@ -237,6 +253,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                                                 : (off == 0 || off > ostart));
             if (ballot64(bad) != 0ull || total + 16 > expected - op || consumed > n - ip) break;
 
+            DPROF_TIME(13);                                             // prefix sum + checks (+ issue of the next window load)
             DPROF_ADD(0, 1);                                            // batches
             DPROF_ADD(1, __builtin_popcountll(tags));                   // tags in batches
             DPROF_ADD(2, total);                                        // output bytes of batches
@@ -303,9 +320,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                     if (!pend) break;
                 }
             }
+            DPROF_TIME(14);                                             // copies (all rounds)
             ip += consumed;
             op += total;
         }
+        DPROF_FLUSH;
         w.wv = 0x80000000u;                                             // force the serial loop to re-seat its window
     }
 
