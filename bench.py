@@ -167,13 +167,24 @@ def main():
         total_u = u_bytes * world
         ms_per_step = elapsed / args.steps * 1e3
         alg = u_bytes + c_bytes                                     # U + C for compress, C + U for decompress
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per
+        # pass, same workload): per-block figures x blocks of this run.  See profiles/r01b_hbm_traffic.json for the caveat
+        # on the gfx950 FETCH_SIZE calibration.
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01b_hbm_traffic.json")) as f:
+                pmc = json.load(f)["kernels"]
+        except OSError:
+            pmc = {}
         def roof(ms, kernel):
             a = alg / (ms * 1e-3) / 1e9
+            t = pmc.get(kernel)
+            traffic = int((t["fetch_bytes_per_block"] + t["write_bytes_per_block"]) * nb) if t and args.hash == "crc32c" else None
             return {"bound": "hbm", "kernel": kernel, "achieved": round(a, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBPS, 5), "traffic": None, "avg_launch_ms": round(ms, 4),
+                    "frac": round(a / HBM_PEAK_GBPS, 5), "traffic": traffic, "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": int(alg),
                     "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}
-        r_c, r_d = roof(ms_c, "k_compress"), roof(ms_d, "k_decompress")
+        r_c = roof(ms_c, "k_compress_lanes" if nb >= 4096 else "k_compress")
+        r_d = roof(ms_d, "k_decompress")
         line = {
             "metric": "uncompressed GB/s block compress+decompress, 64 KiB blocks",
             "value": round(total_u / (elapsed / args.steps) / 1e9, 3),
@@ -181,9 +192,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 10 GiB of 64 KiB html-like blocks per GPU, one block per wavefront, "
+            "config": {"workload": "configs[1]: 10 GiB of 64 KiB html-like blocks per GPU, "
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
+                       "layout": "decompress: one block per wavefront; compress: one fragment per lane (>= 4096 fragments), else one per wavefront",
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,
             "decompress_GBps": round(u_bytes * world / (ms_d * 1e-3) / 1e9, 2) if world == 1 else None,
