@@ -183,7 +183,7 @@ def main():
                     "frac": round(a / HBM_PEAK_GBPS, 5), "traffic": traffic, "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": int(alg),
                     "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}
-        r_c = roof(ms_c, "k_compress_lanes" if nb >= 4096 else "k_compress")
+        r_c = roof(ms_c, "k_compress_lanes" if nb >= 8192 else "k_compress")
         r_d = roof(ms_d, "k_decompress")
         line = {
             "metric": "uncompressed GB/s block compress+decompress, 64 KiB blocks",
@@ -195,7 +195,7 @@ def main():
             "config": {"workload": "configs[1]: 10 GiB of 64 KiB html-like blocks per GPU, "
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
-                       "layout": "decompress: one block per wavefront; compress: one fragment per lane (>= 4096 fragments), else one per wavefront",
+                       "layout": "decompress: one block per wavefront; compress: one fragment per lane (>= 8192 fragments), else one per wavefront",
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,
             "decompress_GBps": round(u_bytes * world / (ms_d * 1e-3) / 1e9, 2) if world == 1 else None,

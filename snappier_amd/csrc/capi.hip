@@ -53,7 +53,7 @@ struct snp_ctx {
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
     int dec_lds = 0;         // dynamic LDS bytes per decode wavefront (occupancy throttle)
     int decode_layout = 0;   // 0/1 wave-per-block (default), 2 block-per-lane (SNAPPIER_HIP_DECODE=lanes)
-    int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= kLanesThreshold), 1 wave-per-fragment, 2 fragment-per-lane
+    int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= 8192 fragments), 1 wave-per-fragment, 2 fragment-per-lane
     DevBuf in, out, meta, work, tables;
     std::string err;
 
@@ -73,7 +73,7 @@ struct snp_ctx {
     bool launch_compress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
                          u32* out_len, i32* status, int emit_varint)
     {
-        const bool lanes = compress_mode == 2 || (compress_mode == 0 && nblocks >= 4096);
+        const bool lanes = compress_mode == 2 || (compress_mode == 0 && nblocks >= 8192);   // measured crossover (scripts/sweep_layouts.py)
         if (!lanes)
             return check(snp_launch_compress(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
                                              emit_varint, stream), "compress launch");

@@ -475,6 +475,42 @@ def test_frame_encode_device_resident(codec):
     assert_same("device framing rt", S.frame_decode(got), raw.cpu().numpy().tobytes())
 
 
+def test_frame_decode_chunks_device_resident(codec):
+    """Device-resident decode of a framed stream from its chunk table: raw and compressed chunks in one launch, every
+    chunk CRC-verified on the device; a flipped CRC or a corrupt body is reported for exactly that chunk."""
+    cd = codec[O.HASH_CRC32C]
+    raw = read_testdata("html") + read_testdata("fireworks.jpeg") + read_testdata("alice29.txt")   # jpeg -> raw (type 1) chunks
+    framed = np.frombuffer(O.frame_encode(raw), dtype=np.uint8).copy()
+    pos, types, boff, blen, crcs = 10, [], [], [], []
+    while pos < framed.size:
+        t = int(framed[pos]); size = int(framed[pos + 1]) | (int(framed[pos + 2]) << 8) | (int(framed[pos + 3]) << 16)
+        types.append(t); crcs.append(int.from_bytes(framed[pos + 4:pos + 8].tobytes(), "little"))
+        boff.append(pos + 8); blen.append(size - 4)
+        pos += 4 + size
+    nc = len(types)
+    assert 1 in types and 0 in types
+    caps = np.minimum(65536, len(raw) - 65536 * np.arange(nc)).astype(np.int32)
+    out_off = (np.arange(nc, dtype=np.int64) * 65536)
+    crc_arr = np.array(crcs, dtype=np.uint32)
+
+    def run(fr, crc):
+        out = torch.zeros(len(raw), dtype=torch.uint8, device="cuda")
+        dlen, dst = cd.frame_decode_chunks(to_dev(fr), to_dev(np.array(types, dtype=np.uint8)), to_dev(np.array(boff, dtype=np.int64)),
+                                           to_dev(np.array(blen, dtype=np.int32)), to_dev(crc.view(np.int32)), out, to_dev(out_off), to_dev(caps))
+        torch.cuda.synchronize()
+        return out.cpu().numpy().tobytes(), dlen.cpu().numpy(), dst.cpu().numpy()
+
+    got, dlen, dst = run(framed, crc_arr)
+    assert (dst == 0).all() and (dlen == caps).all()
+    assert_same("frame chunks", got, raw)
+    bad_crc = crc_arr.copy(); bad_crc[2] ^= 1
+    _g, _l, dst = run(framed, bad_crc)
+    assert dst.tolist() == [0, 0, O.ERR_CRC_MISMATCH] + [0] * (nc - 3)
+    corrupt = framed.copy(); corrupt[boff[0] + 100] ^= 0xFF
+    _g, _l, dst = run(corrupt, crc_arr)
+    assert dst[0] != 0 and (dst[1:] == 0).all()
+
+
 # ------------------------------------------------------------------ full BASELINE size, size-independent properties
 
 @pytest.mark.timeout(1200)
