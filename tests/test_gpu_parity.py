@@ -436,6 +436,35 @@ def test_stream_roundtrip(name):                                   # SnappyStrea
         assert_same(name, z.read(), data)
 
 
+def test_stream_chunk_stress():                                    # SnappyStreamTests.cs:145-192
+    """Random 1..100-byte writes with a Flush after each: hundreds of tiny chunks; every flush boundary becomes a chunk
+    boundary, exactly as SnappyStreamCompressor.Flush (:82-97) does."""
+    import io
+    rng = np.random.default_rng(123)
+    data = rng.integers(0, 256, 9000, dtype=np.uint8).tobytes() + bytes(3000) + read_testdata("html")[:5000]
+    sink = io.BytesIO()
+    pieces, pos = [], 0
+    with S.SnappyStream(sink, S.CompressionMode.Compress, leaveOpen=True) as z:
+        while pos < len(data):
+            k = int(rng.integers(1, 101))
+            z.write(data[pos:pos + k])
+            z.flush()
+            pieces.append(data[pos:pos + k])
+            pos += k
+    framed = sink.getvalue()
+    ref = b"".join(O.frame_encode(p)[10 if i else 0:] for i, p in enumerate(pieces))   # stream identifier only once
+    assert_same("chunk stress", framed, ref)
+    with S.SnappyStream(io.BytesIO(framed), S.CompressionMode.Decompress) as z:
+        out = bytearray()
+        while True:                                                # mid-chunk reads of odd sizes
+            b = z.read(int(rng.integers(1, 777)))
+            if not b:
+                break
+            out += b
+    assert_same("chunk stress rt", bytes(out), data)
+    assert_same("chunk stress oracle", O.frame_decode(framed), data)
+
+
 def test_framing_uncompressed_block_and_rules():                   # SnappyStreamTests.cs:241-262 + format rules
     raw = bytes(range(256))
     s = S.frame_encode(raw)
