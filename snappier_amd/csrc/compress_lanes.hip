@@ -13,6 +13,8 @@
 // SNP_HASH_CRC32C hash (the CRC step is GF(2)-linear, so it factors over the four input bytes; gfx950 has no
 // CRC instruction).  The kernel is bound by random 64-byte-sector traffic to the tables and candidates, not by
 // instruction issue.  Small batches keep using compress.hip (one wavefront per fragment is better there).
+#include <cstdlib>
+
 #include "snp_device.h"
 
 #ifndef SNP_CL_FLAT
@@ -125,11 +127,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
 {
     __shared__ u16 lut[4][256];
     if (VARIANT == SNP_HASH_CRC32C) {
-        for (u32 e = threadIdx.x; e < 1024; e += SNP_WAVE)
+        for (u32 e = threadIdx.x; e < 1024; e += blockDim.x)
             lut[e >> 8][e & 255u] = static_cast<u16>(crc_step32((e & 255u) << (8 * (e >> 8))) & 0x7ffeu);
         __syncthreads();
     }
-    const u32 b = blockIdx.x * SNP_WAVE + threadIdx.x;
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
 
     LaneCtx c;
@@ -326,12 +328,17 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     if (nblocks == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(tables, 0, snp_compress_lanes_workspace(nblocks), stream);   // HashTable.cs:52
     if (e != hipSuccess) return e;
-    const u32 grid = (nblocks + SNP_WAVE - 1) / SNP_WAVE;
+    // Fragments per wavefront: 64 when there are enough fragments to fill the chip that way; fewer (partially filled
+    // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
+    const char* env = getenv("SNAPPIER_HIP_LANES_PER_WAVE");
+    u32 per = env ? static_cast<u32>(atoi(env)) : (nblocks >= 16384 ? 64u : 16u)   // measured: scripts/sweep_layouts.py;
+    if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
+    const u32 grid = (nblocks + per - 1) / per;
     if (variant == SNP_HASH_CRC32C)
-        hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_CRC32C>, dim3(grid), dim3(SNP_WAVE), 0, stream, in, in_off, in_len,
+        hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_CRC32C>, dim3(grid), dim3(per), 0, stream, in, in_off, in_len,
                            nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables));
     else
-        hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_MUL>, dim3(grid), dim3(SNP_WAVE), 0, stream, in, in_off, in_len,
+        hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_MUL>, dim3(grid), dim3(per), 0, stream, in, in_off, in_len,
                            nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables));
     return hipGetLastError();
 }
