@@ -331,7 +331,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // Fragments per wavefront: 64 when there are enough fragments to fill the chip that way; fewer (partially filled
     // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
     const char* env = getenv("SNAPPIER_HIP_LANES_PER_WAVE");
-    u32 per = env ? static_cast<u32>(atoi(env)) : (nblocks >= 16384 ? 64u : 16u)   // measured: scripts/sweep_layouts.py;
+    u32 per = env ? static_cast<u32>(atoi(env)) : (nblocks >= 16384 ? 64u : 16u);   // measured: scripts/sweep_layouts.py
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
     const u32 grid = (nblocks + per - 1) / per;
     if (variant == SNP_HASH_CRC32C)
