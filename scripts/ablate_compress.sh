@@ -8,12 +8,10 @@ V=snappier_amd/variants
 SRC="snappier_amd/csrc/decompress.hip snappier_amd/csrc/decompress_lanes.hip snappier_amd/csrc/compress.hip snappier_amd/csrc/compress_lanes.hip snappier_amd/csrc/crc32c.hip snappier_amd/csrc/framing.hip snappier_amd/csrc/capi.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fconstexpr-steps=100000000 -Wno-unused-function -Wl,-rpath,/opt/rocm/lib"
 declare -A VARIANTS=(
-  [slots1]="-DSNP_CL_SLOTS=1"
-  [slots2]="-DSNP_CL_SLOTS=2"
-  [slots3]="-DSNP_CL_SLOTS=3"
-  [slots4]="-DSNP_CL_SLOTS=4"
-  [slots6]="-DSNP_CL_SLOTS=6"
-  [slots8]="-DSNP_CL_SLOTS=8"
+  [rounds1]="-DSNP_D_ROUNDS=1"
+  [rounds2]="-DSNP_D_ROUNDS=2"
+  [rounds3]="-DSNP_D_ROUNDS=3"
+  [rounds5]="-DSNP_D_ROUNDS=5"
 )
 if [ "$1" = prof ]; then
   mkdir -p $V

@@ -120,6 +120,10 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
     }
 }
 
+#ifndef SNP_D_ROUNDS
+#define SNP_D_ROUNDS 1      // lane-parallel dependency rounds per batch before the rest is finished tag by tag (measured: 1 > 2 > 3)
+#endif
+
 // ---- optional event counters (build with -DSNP_D_PROF=1; scripts/prof_decompress.py) --------------------------------
 #ifndef SNP_D_PROF
 #define SNP_D_PROF 0
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
             u32 mark = op;                                              // all output below `mark` is complete
             for (u32 round = 0;; ++round) {
                 DPROF_ADD(3, 1);                                        // rounds (incl. the finishing pass)
-                if (round == 3) {
+                if (round == SNP_D_ROUNDS) {
                     DPROF_ADD(4, __builtin_popcountll(pend));           // tags finished one by one
                     // a long dependency chain inside the batch: finish it tag by tag, whole wave per tag
                     while (pend) {
