@@ -8,10 +8,10 @@ V=snappier_amd/variants
 SRC="snappier_amd/csrc/decompress.hip snappier_amd/csrc/decompress_lanes.hip snappier_amd/csrc/compress.hip snappier_amd/csrc/compress_lanes.hip snappier_amd/csrc/crc32c.hip snappier_amd/csrc/framing.hip snappier_amd/csrc/capi.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fconstexpr-steps=100000000 -Wno-unused-function -Wl,-rpath,/opt/rocm/lib"
 declare -A VARIANTS=(
-  [rounds1]="-DSNP_D_ROUNDS=1"
-  [rounds2]="-DSNP_D_ROUNDS=2"
-  [rounds3]="-DSNP_D_ROUNDS=3"
-  [rounds5]="-DSNP_D_ROUNDS=5"
+  [passes0]="-DSNP_D_PASSES=0"
+  [passes1]="-DSNP_D_PASSES=1"
+  [passes2]="-DSNP_D_PASSES=2"
+  [passes3]="-DSNP_D_PASSES=3"
 )
 if [ "$1" = prof ]; then
   mkdir -p $V

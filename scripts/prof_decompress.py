@@ -18,7 +18,7 @@ L.snp_debug_read_dprof(buf, 1)
 cd.decompress(out, out_off, out_len, back, in_off, in_len)
 torch.cuda.synchronize()
 L.snp_debug_read_dprof(buf, 1)
-names = ["batches", "tags in batches", "output bytes in batches", "rounds", "tags finished one by one", "tags round0",
+names = ["batches (queued: execution batches)", "tags in batches", "output bytes in batches", "rounds", "tags finished one by one", "tags round0",
          "tags round1", "tags round2", "pattern copies (coop)", "tags in serial loop"]
 for k, nme in enumerate(names):
     print(f"{nme:28s} {buf[k]/nb:12.1f} per block")

@@ -128,6 +128,7 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->fenced = (f && f[0] == '1') ? 1 : 0;
     const char* m = getenv("SNAPPIER_HIP_DECODE");
     if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
+    if (m && strcmp(m, "batched") == 0) c->fenced |= 4;                 // token-parallel batches without the execution queue
     c->decode_layout = (m && strcmp(m, "lanes") == 0) ? 2 : (m && (strcmp(m, "serial") == 0 || strcmp(m, "batched") == 0)) ? 1 : 0;
     // SNAPPIER_HIP_DEC_LDS=<bytes>: dynamic LDS per decode wavefront, an occupancy throttle (160 KiB / bytes blocks per CU)
     const char* dl = getenv("SNAPPIER_HIP_DEC_LDS");

@@ -120,6 +120,9 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
     }
 }
 
+#ifndef SNP_D_PASSES
+#define SNP_D_PASSES 1      // queued mode: extra lane-parallel passes over pending tags before the serial finish
+#endif
 #ifndef SNP_D_ROUNDS
 #define SNP_D_ROUNDS 1      // lane-parallel dependency rounds per batch before the rest is finished tag by tag (measured: 1 > 2 > 3)
 #endif
@@ -147,7 +150,7 @@ __device__ unsigned long long g_dprof[16];
 #define DPROF_FLUSH
 #endif
 
-template <bool FENCED, bool BATCHED>
+template <bool FENCED, int FRONT>   // FRONT: 0 serial loop only, 1 token-parallel batches, 2 batches feeding a 64-tag execution queue
 __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                         const u32* __restrict__ in_len, u32 nblocks, u8* out,
                                                         const u64* __restrict__ out_off,
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
     }
 
     // ---- token-parallel batches (see the header) ------------------------------------------------------------------
-    if (BATCHED) {
+    if (FRONT == 1) {
         // the next batch's input window is requested as soon as this batch's length is known, so its latency overlaps
         // this batch's copies
         u64 q_next = (st == SNP_OK && ip + 72 <= n) ? ld64u(src + ip + lane) : 0ull;
@@ -332,6 +335,147 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
         w.wv = 0x80000000u;                                             // force the serial loop to re-seat its window
     }
 
+    // ---- token-parallel parse feeding an execution queue -----------------------------------------------------------------
+    // Every vector-memory instruction costs the texture-address unit ~16 cycles whether 5 or 64 of its lanes are active,
+    // and a 64-byte window holds only ~21 tags.  So windows are parsed as above but their tags are appended to a queue
+    // in LDS, and copies are executed 64 tags at a time: the same ~10 memory instructions then serve three windows.
+    if (FRONT == 2) {
+        __shared__ u32 q_ostart[128], q_arg[128], q_meta[128];          // ring: output offset | copy offset or literal
+        u32 head = 0, count = 0;                                        // input position | length + literal flag
+        bool parsing = st == SNP_OK;
+        u64 q_next = (parsing && ip + 72 <= n) ? ld64u(src + ip + lane) : 0ull;
+        for (;;) {
+            head = bcast_first(head);
+            count = bcast_first(count);
+            if (parsing && count <= 64 && ip + 72 <= n && op < expected) {
+                // ---- parse one 64-byte window (steps 1-3 of the batched path) ----
+                const u64 q = q_next;
+                const u32 c = static_cast<u32>(q) & 0xffu;
+                const u32 type = c & 3u;
+                const u32 hi6 = c >> 2;
+                const u32 b1234 = static_cast<u32>(q >> 8);
+                const u32 extra = type == 0 ? (hi6 >= 60 ? hi6 - 59 : 0) : (type == 3 ? 4 : type);
+                const u32 trailer = extra >= 4 ? b1234 : (b1234 & ((1u << (8 * extra)) - 1u));
+                u32 len, off = 0;
+                if (type == 0) len = hi6 >= 60 ? trailer + 1 : hi6 + 1;
+                else if (type == 1) { len = (hi6 & 7u) + 4; off = ((c >> 5) << 8) | (b1234 & 0xffu); }
+                else { len = hi6 + 1; off = trailer; }
+                const u32 body = lane + 1 + extra;
+                const u32 n1 = body + (type == 0 ? min(len, 0x40000000u) : 0);
+                const u32 h2 = bperm(n1, n1);
+                const u32 n2 = n1 < 64 ? h2 : n1;
+                const u32 h3 = bperm(n1, n2);
+                const u32 n3 = n1 < 64 ? h3 : n1;
+                const u32 h4 = bperm(n2, n2);
+                const u32 n4 = n2 < 64 ? h4 : n2;
+                u64 tags = 0;
+                u32 pos = 0;
+                do {
+                    const u32 a = read_lane(n1, pos), bq = read_lane(n2, pos), cq = read_lane(n3, pos), dq = read_lane(n4, pos);
+                    tags |= ballot64(lane == pos || lane == a || lane == bq || lane == cq);
+                    pos = dq;
+                } while (pos < 64);
+                const u32 consumed = pos;
+                if (consumed <= n - ip && ip + consumed + 72 <= n) q_next = ld64u(src + ip + consumed + lane);
+                const bool real = (tags >> lane) & 1ull;
+                const u32 olen = real ? len : 0u;
+                const u32 incl = wave_inclusive_scan(olen);
+                const u32 total = read_lane(incl, 63);
+                const u32 ostart = op + incl - olen;
+                const bool is_lit = type == 0;
+                const bool bad = real && (is_lit ? (len == 0 || len + 16 > n - ip || body > n - ip - len - 16)
+                                                 : (off == 0 || off > ostart));
+                if (ballot64(bad) != 0ull || total + 16 > expected - op || consumed > n - ip) { parsing = false; continue; }
+                // literals longer than 64 bytes do not depend on anything: whole-wave memcpy right away
+                u64 big = ballot64(real && is_lit && len > 64);
+                const u64 enq = tags & ~big;
+                while (big) {
+                    const u32 t = static_cast<u32>(__builtin_ctzll(big));
+                    big &= big - 1;
+                    wave_copy(dst + read_lane(ostart, t), src + ip + read_lane(body, t), read_lane(len, t), lane);
+                }
+                // append the window's tags to the queue, in order
+                if ((enq >> lane) & 1ull) {
+                    const u32 slot = (head + count + static_cast<u32>(__builtin_popcountll(enq & lanes_below(lane)))) & 127u;
+                    q_ostart[slot] = ostart;
+                    q_arg[slot] = is_lit ? ip + body : off;
+                    q_meta[slot] = len | (is_lit ? 0x100u : 0u);
+                }
+                count += static_cast<u32>(__builtin_popcountll(enq));
+                ip += consumed;
+                op += total;
+                continue;
+            }
+            if (count == 0) break;
+            // ---- execute up to 64 queued tags: one lane-parallel pass, then dependent tags one by one ----
+            asm volatile("" ::: "memory");                              // the queue was written by other lanes
+            const u32 ne = count < 64 ? count : 64u;
+            const bool act = lane < ne;
+            const u32 slot = (head + lane) & 127u;
+            const u32 e_ostart = q_ostart[slot], e_arg = q_arg[slot], e_meta = q_meta[slot];
+            const u32 e_len = e_meta & 0xffu;
+            const bool e_lit = (e_meta & 0x100u) != 0;
+            const u32 e_off = e_lit ? 0u : e_arg;
+            const u32 mark = read_lane(e_ostart, 0);                    // everything before the first queued tag is complete
+            const bool ready = act && (e_lit || (e_off >= e_len && e_ostart - e_off + e_len <= mark));
+            if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ready) lane_copy(dst + e_ostart, e_lit ? src + e_arg : dst + (e_ostart - e_off), e_len);
+            u64 pend = ballot64(act && !ready);
+            DPROF_ADD(0, 1);                                            // execution batches
+            DPROF_ADD(1, ne);                                           // tags executed
+            DPROF_ADD(5, __builtin_popcountll(pend));                   // tags not ready in the first pass
+            // More lane-parallel passes: a pending copy may run as soon as its source no longer overlaps the output of
+            // another pending tag (those bytes do not exist yet).  Most near copies read what an earlier pass just wrote;
+            // each pass peels one level off every dependency chain.  Pattern copies go through the serial finish.
+            const u32 s_lo = e_ostart - e_off, s_hi = s_lo + e_len;
+#define SNP_D_EXTRA_PASS                                                                                             \
+            if (pend & (pend - 1)) {                                                                                 \
+                bool blocked = e_off < e_len;                                                                        \
+                u64 it = pend;                                                                                       \
+                while (it) {                                                                                         \
+                    const u32 f = static_cast<u32>(__builtin_ctzll(it));                                             \
+                    it &= it - 1;                                                                                    \
+                    const u32 f_o = read_lane(e_ostart, f), f_end = f_o + read_lane(e_len, f);                       \
+                    blocked = blocked || (lane > f && s_lo < f_end && s_hi > f_o);                                   \
+                }                                                                                                    \
+                const bool ready2 = ((pend >> lane) & 1ull) && !blocked;                                             \
+                if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+                if (ready2) lane_copy(dst + e_ostart, dst + s_lo, e_len);                                            \
+                pend &= ~ballot64(ready2);                                                                           \
+            }
+#if SNP_D_PASSES >= 1
+            SNP_D_EXTRA_PASS
+#endif
+#if SNP_D_PASSES >= 2
+            SNP_D_EXTRA_PASS
+#endif
+#if SNP_D_PASSES >= 3
+            SNP_D_EXTRA_PASS
+#endif
+#undef SNP_D_EXTRA_PASS
+            DPROF_ADD(4, __builtin_popcountll(pend));                   // tags finished one by one
+            while (pend) {
+                const u32 f = static_cast<u32>(__builtin_ctzll(pend));
+                pend &= pend - 1;
+                const u32 f_o = read_lane(e_ostart, f), f_off = read_lane(e_off, f), f_len = read_lane(e_len, f);
+                if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                u32 sidx = lane;
+                if (f_off < f_len) {
+#pragma unroll
+                    for (int sh = 5; sh >= 0; --sh) {
+                        const u32 t = f_off << sh;
+                        sidx = min(sidx, sidx - t);
+                    }
+                }
+                if (lane < f_len) dst[f_o + lane] = dst[f_o - f_off + sidx];
+            }
+            asm volatile("" ::: "memory");
+            head = (head + ne) & 127u;
+            count -= ne;
+        }
+        w.wv = 0x80000000u;
+    }
+
     u32 fenced = 0;   // output bytes below this are known to have left the wave's store queue (FENCED only)
 
     // ---- tag loop  (SnappyDecompressor.cs:234-341) -----------------------------------------------------------
@@ -414,18 +558,20 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
                                             const u64* out_off, const u32* out_cap, u32* out_len, i32* status,
                                             const u8* chunk_type, int mode, hipStream_t stream)
 {
-    // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end); bits 8..: dynamic LDS bytes / 256 requested
-    // per wavefront purely to cap how many blocks a CU decodes at once (keeps their outputs cache resident)
+    // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end), bit 2: batches without the execution queue;
+    // bits 8..: dynamic LDS bytes / 256 requested per wavefront purely to cap how many blocks a CU decodes at once
     if (nblocks == 0) return hipSuccess;
     const unsigned lds_bytes = static_cast<unsigned>(mode >> 8) * 256u;
 #define SNP_LAUNCH_DEC(F, B)                                                                                        \
     hipLaunchKernelGGL((k_decompress<F, B>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,   \
                        nblocks, out, out_off, out_cap, out_len, status, chunk_type)
-    switch (mode & 3) {
-        case 0: SNP_LAUNCH_DEC(false, true); break;
-        case 1: SNP_LAUNCH_DEC(true, true); break;
-        case 2: SNP_LAUNCH_DEC(false, false); break;
-        default: SNP_LAUNCH_DEC(true, false); break;
+    switch (mode & 7) {
+        case 0: SNP_LAUNCH_DEC(false, 2); break;
+        case 1: SNP_LAUNCH_DEC(true, 2); break;
+        case 2: case 6: SNP_LAUNCH_DEC(false, 0); break;
+        case 3: case 7: SNP_LAUNCH_DEC(true, 0); break;
+        case 4: SNP_LAUNCH_DEC(false, 1); break;
+        default: SNP_LAUNCH_DEC(true, 1); break;
     }
 #undef SNP_LAUNCH_DEC
     return hipGetLastError();
