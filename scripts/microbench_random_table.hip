@@ -1,0 +1,110 @@
+// microbench_random_table.hip -- what the memory system gives the lane compressor's hash-table access pattern.
+// Every lane owns a private 64 KiB table (16384 x u32) in HBM, exactly like k_compress_lanes' workspace, and runs a
+// chain of DEPENDENT probes: h = hash(state); v = table[h]; table[h] = i; state = f(state, v).  No input, no output,
+// no compare: just the table traffic of `probes` probes per fragment.  Prints probes/s and the time 10 600 probes per
+// fragment (the html-like workload's measured average) would take over 163 840 fragments.
+//   hipcc --offload-arch=gfx950 -O3 scripts/microbench_random_table.hip -o scripts/_bin/microbench_random_table
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// MODE 0: read only; 1: read + write same entry; 2: write only (entry never read: a partial-sector write);
+//      3: read + non-temporal write; 4: non-temporal read + write;
+//      5/6/7: read the entry, then write back the whole aligned 16 / 64 / 32 bytes around it (is a partially dirty
+//      sector a DRAM read-modify-write?)
+template <int ILP, int MODE>
+__global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint32_t nfrag, uint32_t probes, uint32_t* __restrict__ sink)
+{
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= nfrag) return;
+    uint32_t* t = tables + static_cast<uint64_t>(g) * 16384u;
+    uint32_t st[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) st[k] = g * 2654435761u + k * 40503u + 1u;
+    for (uint32_t i = 0; i < probes; i += ILP) {
+        uint32_t v[ILP], h[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {
+            h[k] = (st[k] * 0x1e35a7bdu) >> 18;
+            v[k] = MODE == 2 ? 0u : MODE == 4 ? __builtin_nontemporal_load(t + h[k]) : t[h[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) {
+            if (MODE == 1 || MODE == 2 || MODE == 4) t[h[k]] = i + k;
+            if (MODE == 3) __builtin_nontemporal_store(i + k, t + h[k]);
+            if (MODE >= 5) {
+                constexpr uint32_t W = MODE == 5 ? 4 : MODE == 6 ? 16 : 8;     // dwords
+                uint4* q = reinterpret_cast<uint4*>(t + (h[k] & ~(W - 1)));
+                uint4 x[W / 4];
+#pragma unroll
+                for (uint32_t j = 0; j < W / 4; ++j) x[j] = q[j];
+                x[0].x += i + k + v[k];
+#pragma unroll
+                for (uint32_t j = 0; j < W / 4; ++j) q[j] = x[j];
+            }
+            st[k] = st[k] * 1664525u + 1013904223u + v[k];
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; ++k) acc ^= st[k];
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int ILP, int MODE>
+static void run(uint32_t* tables, uint32_t* sink, uint32_t nfrag, uint32_t probes, const char* name)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipMemsetAsync(tables, 0, static_cast<size_t>(nfrag) * 65536, 0));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL((k_walk<ILP, MODE>), dim3((nfrag + 63) / 64), dim3(64), 0, 0, tables, nfrag, probes, sink);
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (rep == 1) {
+            const double total = static_cast<double>(nfrag) * probes;
+            printf("{\"case\": \"%s\", \"fragments\": %u, \"probes_per_fragment\": %u, \"ms\": %.3f, \"Gprobes_per_s\": %.2f, "
+                   "\"ms_for_10600_probes_x_163840\": %.1f}\n", name, nfrag, probes, ms, total / ms / 1e6,
+                   10600.0 * 163840.0 / (total / ms));
+            fflush(stdout);
+        }
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const uint32_t nfrag = argc > 1 ? atoi(argv[1]) : 163840;
+    const uint32_t probes = argc > 2 ? atoi(argv[2]) : 4096;
+    uint32_t *tables, *sink;
+    CK(hipMalloc(&tables, static_cast<size_t>(nfrag) * 65536));
+    CK(hipMalloc(&sink, 64));
+    {
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        CK(hipMemsetAsync(tables, 0, static_cast<size_t>(nfrag) * 65536, 0));
+        CK(hipEventRecord(a, 0));
+        CK(hipMemsetAsync(tables, 0, static_cast<size_t>(nfrag) * 65536, 0));
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("{\"case\": \"memset tables\", \"bytes\": %zu, \"ms\": %.3f}\n", static_cast<size_t>(nfrag) * 65536, ms);
+    }
+    if (argc > 3) {      // cache-resident sweep: few fragments, many chains
+        run<1, 1>(tables, sink, nfrag, probes, "read+write, 1 chain per lane");
+        run<8, 1>(tables, sink, nfrag, probes, "read+write, 8 chains per lane");
+        run<8, 0>(tables, sink, nfrag, probes, "read only, 8 chains per lane");
+        return 0;
+    }
+    run<1, 0>(tables, sink, nfrag, probes, "read only, 1 chain per lane");
+    run<1, 1>(tables, sink, nfrag, probes, "read+write, 1 chain per lane");
+    run<4, 1>(tables, sink, nfrag, probes, "read+write, 4 chains per lane");
+    run<1, 2>(tables, sink, nfrag, probes, "write only (no read of the sector), 1 chain per lane");
+    run<1, 5>(tables, sink, nfrag, probes, "read + write back aligned 16 B, 1 chain per lane");
+    run<1, 7>(tables, sink, nfrag, probes, "read + write back aligned 32 B, 1 chain per lane");
+    run<1, 6>(tables, sink, nfrag, probes, "read + write back aligned 64 B, 1 chain per lane");
+    return 0;
+}

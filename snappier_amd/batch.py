@@ -77,13 +77,19 @@ class BlockCodec:
         return crc
 
     # -- framing, device resident (config 4) --------------------------------------------------------------------
-    def frame_encode(self, raw: torch.Tensor):
-        """-> (framed tensor (capacity-sized), written: 1-element int64 tensor on device)."""
+    def frame_encode(self, raw: torch.Tensor, out: torch.Tensor | None = None, work: torch.Tensor | None = None):
+        """-> (framed tensor (capacity-sized), written: 1-element int64 tensor on device).  `out` / `work` may be
+        passed in to reuse buffers across calls (sizes: snp_frame_max_encoded_length / snp_frame_encode_workspace)."""
         self._bind()
         n = raw.numel()
         cap = N.lib().snp_frame_max_encoded_length(n)
-        out = torch.empty(cap, dtype=torch.uint8, device=self.device)
-        work = torch.empty(N.lib().snp_frame_encode_workspace(n), dtype=torch.uint8, device=self.device)
+        need = N.lib().snp_frame_encode_workspace(n)
+        if out is None:
+            out = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        if work is None:
+            work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if out.numel() < cap or work.numel() < need:
+            raise ValueError("frame_encode: out/work buffers too small")
         written = torch.zeros(1, dtype=torch.int64, device=self.device)
         st = N.lib().snp_frame_encode_device(self.ctx.handle, _p(raw), n, _p(out), cap, _p(written), _p(work))
         raise_for_status(st, self.ctx.handle)
