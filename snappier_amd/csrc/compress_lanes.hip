@@ -82,6 +82,40 @@ __device__ __forceinline__ u32 lane_emit_literal(const LaneCtx& c, u32 op, u32 s
     return op + hdr + len;
 }
 
+// EmitLiteral (:418-464) with the first 16 bytes of the literal already in registers (`first`): a literal of <= 16 bytes
+// costs no load at all.  `cap` > 0: the lane's output area holds MaxCompressedLength bytes, so a 16-byte store that
+// overshoots the literal is harmless (the next tag overwrites the excess) whenever it still ends inside the area.
+__device__ __forceinline__ u32 lane_emit_literal16(const LaneCtx& c, u32 op, u32 s, u32 len, const snp_u128_unaligned& first, u32 cap)
+{
+    u8* o = c.dst + op;
+    const u32 k = len - 1;
+    u32 hdr;
+    if (k < 60) { o[0] = static_cast<u8>(k << 2); hdr = 1; }
+    else if (k < 256) { o[0] = static_cast<u8>(60u << 2); o[1] = static_cast<u8>(k); hdr = 2; }
+    else { o[0] = static_cast<u8>(61u << 2); o[1] = static_cast<u8>(k); o[2] = static_cast<u8>(k >> 8); hdr = 3; }   // k < 65536
+    u8* d = o + hdr;
+    if (len >= 16 || op + hdr + 16 <= cap) {
+        *reinterpret_cast<snp_u128_unaligned*>(d) = first;
+    } else {                                                           // exact-length stores cut out of the registers
+        u32 w[4] = {first.v[0], first.v[1], first.v[2], first.v[3]};
+        u32 at = 0, wi = 0;
+        if (len & 8) { st32u(d, w[0]); st32u(d + 4, w[1]); at = 8; wi = 2; }
+        if (len & 4) { st32u(d + at, w[wi]); at += 4; ++wi; }
+        u32 rest = w[wi & 3];
+        if (len & 2) { d[at] = static_cast<u8>(rest); d[at + 1] = static_cast<u8>(rest >> 8); rest >>= 16; at += 2; }
+        if (len & 1) d[at] = static_cast<u8>(rest);
+    }
+    if (len > 16) {
+        const u8* src = c.src + s;
+        u32 i = 16;
+        for (; i + 16 <= len; i += 16)
+            *reinterpret_cast<snp_u128_unaligned*>(d + i) = *reinterpret_cast<const snp_u128_unaligned*>(src + i);
+        if (i < len)                                                   // the tail, as one 16-byte piece ending at len
+            *reinterpret_cast<snp_u128_unaligned*>(d + len - 16) = *reinterpret_cast<const snp_u128_unaligned*>(src + len - 16);
+    }
+    return op + hdr + len;
+}
+
 // EmitCopyAtMost64*  SnappyCompressor.cs:467-505
 __device__ __forceinline__ u32 lane_emit_copy64(u8* dst, u32 op, u32 off, u32 len)
 {
@@ -123,7 +157,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                                                             const u32* __restrict__ in_len, u32 nblocks,
                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
                                                             u32* __restrict__ out_len, i32* __restrict__ status,
-                                                            int emit_varint, u32* __restrict__ tables)
+                                                            int emit_varint, u32* __restrict__ tables, int lit_blind)
 {
     __shared__ u16 lut[4][256];
     if (VARIANT == SNP_HASH_CRC32C) {
@@ -167,105 +201,179 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
         mode = kScan;                                                  // first outer iteration: next_emit = 0, ip = 1  :198-199
         ip = 1;
     }
+    // Every trip of the loop is three dependent memory round trips, whatever the lanes are doing:
+    //   trip 1: the input bytes of this lane's probes (one 8-byte load covers ip-1 / ip / ip+1..4)  |  the next 32 + 32
+    //           bytes of a running match extension;
+    //   trip 2: the table entries of the probes;
+    //   trip 3: for the first probe whose entry can match (check bits agree): 16 bytes at the candidate, 16 bytes at
+    //           the probe and the first 16 bytes of the pending literal -- so a hit is confirmed, its literal emitted
+    //           from registers and a match shorter than 16 finished without another trip.
+    // (The first version waited for each of these in turn plus a load per literal piece and four extension steps:
+    // ~10 trips per loop trip, and the loop trip is what 64 lanes pay together.)
+    const u32 lit_cap = lit_blind ? 32u + n + n / 6u : 0u;            // blind 16-byte literal stores stay inside MaxCompressedLength
     while (__any(mode != kDone)) {
-        if (mode == kScan || mode == kPost) {
-            // A group of up to kSlots consecutive probes of this lane's scan, issued together so that their table and
-            // candidate loads overlap (the serial chain is d -> table[h] -> src[candidate]); the group is then resolved
-            // in order, and only the probes the serial algorithm really reaches commit their table writes.  A probe
-            // right after a copy (kPost) is a group of one, preceded by the insertion of ip-1.
-            const bool post = mode == kPost;
-            u32 p[kSlots], nx[kSlots], sk[kSlots], d[kSlots], h[kSlots], cv[kSlots], e[kSlots];
-            bool legal[kSlots];
-            {
-                u32 q = ip, s = skip;
-                bool ok = true;
+        const bool post = mode == kPost;
+        const bool scanning = mode == kScan || post;
+        u32 p[kSlots], nx[kSlots], sk[kSlots], d[kSlots], h[kSlots], cv[kSlots];
+        bool legal[kSlots];
+        u64 w0 = 0;
+        if (scanning) {
+            u32 q = ip, sv = skip;
+            bool ok = true;
 #pragma unroll
-                for (u32 k = 0; k < kSlots; ++k) {
-                    const u32 bb = post ? 0u : s >> 5;                  // :319
-                    s += bb;
-                    p[k] = q;
-                    nx[k] = q + bb;
-                    sk[k] = s;
-                    ok = ok && (post ? k == 0 : nx[k] <= limit);        // :323
-                    legal[k] = ok;
-                    q = nx[k];
+            for (u32 k = 0; k < kSlots; ++k) {
+                const u32 bb = post ? 0u : sv >> 5;                     // :319
+                sv += bb;
+                p[k] = q;
+                nx[k] = q + bb;
+                sk[k] = sv;
+                ok = ok && (post ? k == 0 : nx[k] <= limit);            // :323
+                legal[k] = ok;
+                q = nx[k];
+            }
+            w0 = ld64u(c.src + ip - (post ? 1u : 0u));                  // ip <= limit = n - 15: in bounds
+        } else {
+#pragma unroll
+            for (u32 k = 0; k < kSlots; ++k) { p[k] = nx[k] = sk[k] = 0; legal[k] = false; }
+        }
+        // ---- trip 1, extension side -------------------------------------------------------------------------------
+        const bool ext = mode == kExtend;
+        const bool ext_wide = ext && base + mlen + 32 <= n;
+        snp_u128_unaligned xa0 = {}, xa1 = {}, xb0 = {}, xb1 = {};
+        if (ext_wide) {
+            const u8* a = c.src + cand + mlen;
+            const u8* bq = c.src + base + mlen;
+            xa0 = *reinterpret_cast<const snp_u128_unaligned*>(a);
+            xa1 = *reinterpret_cast<const snp_u128_unaligned*>(a + 16);
+            xb0 = *reinterpret_cast<const snp_u128_unaligned*>(bq);
+            xb1 = *reinterpret_cast<const snp_u128_unaligned*>(bq + 16);
+        }
+        // ---- trip 2: hashes and table entries ----------------------------------------------------------------------
+        if (scanning) {
+            if (post) {                                                 // :393-394
+                const u32 dm1 = static_cast<u32>(w0);
+                c.table[lane_hash<VARIANT>(c, dm1, lut)] = (ip - 1) | check_bits(dm1);
+                d[0] = static_cast<u32>(w0 >> 8);
+            } else {
+                d[0] = static_cast<u32>(w0);
+            }
+#pragma unroll
+            for (u32 k = 1; k < kSlots; ++k) {
+                d[k] = 0;
+                if (legal[k]) {
+                    const u32 delta = p[k] - p[0];
+                    d[k] = delta <= 4 ? static_cast<u32>(w0 >> (8 * delta)) : ld32u(c.src + p[k]);
                 }
             }
-            if (post) {                                                 // :393-394
-                const u32 dm1 = ld32u(c.src + ip - 1);
-                c.table[lane_hash<VARIANT>(c, dm1, lut)] = (ip - 1) | check_bits(dm1);
-            }
-#pragma unroll
-            for (u32 k = 0; k < kSlots; ++k) d[k] = legal[k] ? ld32u(c.src + p[k]) : 0u;
 #pragma unroll
             for (u32 k = 0; k < kSlots; ++k) h[k] = lane_hash<VARIANT>(c, d[k], lut);
 #pragma unroll
             for (u32 k = 0; k < kSlots; ++k) cv[k] = legal[k] ? c.table[h[k]] : 0u;   // :329 / :396  (position | check bits)
-            // a later probe of the group falling into the bucket of an earlier one sees that probe's entry
-#pragma unroll
-            for (u32 k = 1; k < kSlots; ++k)
-#pragma unroll
-                for (u32 i = 0; i < k; ++i)
-                    if (legal[k] && h[i] == h[k]) cv[k] = p[i] | check_bits(d[i]);
-#pragma unroll
-            for (u32 k = 0; k < kSlots; ++k) {
-                const u32 pos = cv[k] & 0xffffu;
-                e[k] = ~d[k];
-                if (legal[k]) {
-                    if (pos == 0) e[k] = c.first4;
-                    else if ((cv[k] & 0xffff0000u) == check_bits(d[k])) e[k] = ld32u(c.src + pos);
-                }
-                cv[k] = pos;
-            }
-            // in-order resolution
-            bool hit = false, ended = false;
-#pragma unroll
-            for (u32 k = 0; k < kSlots; ++k) {
-                if (!hit && !ended) {
-                    if (!legal[k]) {
-                        ended = true;
-                        if (!post) { ip = next_emit; mode = kDone; }    // :323-327 -> emit_remainder
-                    } else {
-                        c.table[h[k]] = p[k] | check_bits(d[k]);        // :333 / :397
-                        if (e[k] == d[k]) {                             // :334 / :398
-                            hit = true;
-                            if (!post) op = lane_emit_literal(c, op, next_emit, p[k] - next_emit);   // :347
-                            base = p[k];
-                            cand = cv[k];
-                            mlen = 4;
-                            mode = kExtend;
-                        }
-                    }
-                }
-            }
-            if (!hit && mode != kDone) {
-                if (post) {                                             // the probe after a copy missed: next outer iteration
-                    next_emit = ip;
-                    ++ip;
-                    skip = 32;
-                    mode = kScan;
-                } else {                                                // all kSlots probes missed  :339-340
-                    ip = nx[kSlots - 1];
-                    skip = sk[kSlots - 1];
-                }
-            }
         }
-        if (mode == kExtend) {                                         // FindMatchLength  :562-688, 32 bytes per trip
+        // ---- extension: compare what trip 1 brought (while the table entries are in flight) -----------------------
+        if (ext) {
             bool finished = false;
-            for (u32 k = 0; k < 4 && !finished; ++k) {
-                if (base + mlen + 8 <= n) {
-                    const u64 x = ld64u(c.src + cand + mlen) ^ ld64u(c.src + base + mlen);
-                    if (x) { mlen += static_cast<u32>(__builtin_ctzll(x)) >> 3; finished = true; }
-                    else mlen += 8;
-                } else {
-                    while (base + mlen < n && c.src[cand + mlen] == c.src[base + mlen]) ++mlen;
-                    finished = true;
+            if (ext_wide) {
+                const u64 x0 = (static_cast<u64>(xa0.v[0] ^ xb0.v[0])) | (static_cast<u64>(xa0.v[1] ^ xb0.v[1]) << 32);
+                const u64 x1 = (static_cast<u64>(xa0.v[2] ^ xb0.v[2])) | (static_cast<u64>(xa0.v[3] ^ xb0.v[3]) << 32);
+                const u64 x2 = (static_cast<u64>(xa1.v[0] ^ xb1.v[0])) | (static_cast<u64>(xa1.v[1] ^ xb1.v[1]) << 32);
+                const u64 x3 = (static_cast<u64>(xa1.v[2] ^ xb1.v[2])) | (static_cast<u64>(xa1.v[3] ^ xb1.v[3]) << 32);
+                finished = true;
+                if (x0) mlen += static_cast<u32>(__builtin_ctzll(x0)) >> 3;
+                else if (x1) mlen += 8 + (static_cast<u32>(__builtin_ctzll(x1)) >> 3);
+                else if (x2) mlen += 16 + (static_cast<u32>(__builtin_ctzll(x2)) >> 3);
+                else if (x3) mlen += 24 + (static_cast<u32>(__builtin_ctzll(x3)) >> 3);
+                else { mlen += 32; finished = false; }
+            } else {                                                    // the last < 32 bytes of the fragment  :562-688
+                for (u32 k = 0; k < 4 && !finished; ++k) {
+                    if (base + mlen + 8 <= n) {
+                        const u64 x = ld64u(c.src + cand + mlen) ^ ld64u(c.src + base + mlen);
+                        if (x) { mlen += static_cast<u32>(__builtin_ctzll(x)) >> 3; finished = true; }
+                        else mlen += 8;
+                    } else {
+                        while (base + mlen < n && c.src[cand + mlen] == c.src[base + mlen]) ++mlen;
+                        finished = true;
+                    }
                 }
             }
             if (finished) {
                 ip = base + mlen;
                 op = lane_emit_copy(c.dst, op, base - cand, mlen);     // :371-379
                 mode = ip >= limit ? kDone : kPost;                    // :381-384
+            }
+        }
+        // ---- trip 3: candidate / probe / literal bytes for the first probe that can match -------------------------
+        if (scanning) {
+            // a later probe of the group falling into the bucket of an earlier one sees that probe's entry
+#pragma unroll
+            for (u32 k = 1; k < kSlots; ++k)
+#pragma unroll
+                for (u32 i = 0; i < k; ++i)
+                    if (legal[k] && h[i] == h[k]) cv[k] = p[i] | check_bits(d[i]);
+            u32 kw = kSlots;                                            // first probe whose entry can match
+#pragma unroll
+            for (u32 k = kSlots; k-- > 0;) {
+                const u32 pos = cv[k] & 0xffffu;
+                const bool want = legal[k] && (pos == 0 ? c.first4 == d[k] : (cv[k] & 0xffff0000u) == check_bits(d[k]));
+                if (want) kw = k;
+            }
+            u32 wp = 0, wpos = 0;
+#pragma unroll
+            for (u32 k = 0; k < kSlots; ++k)
+                if (kw == k) { wp = p[k]; wpos = cv[k] & 0xffffu; }
+            snp_u128_unaligned cb = {}, pb = {}, lb = {};
+            if (kw < kSlots) {                                          // wpos < wp <= n - 16: all three loads in bounds
+                cb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + wpos);
+                pb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + wp);
+                if (!post) lb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + next_emit);
+            }
+            // in-order resolution: probes before kw missed, kw is decided by the bytes, probes after it did not happen
+            bool ended = false;
+#pragma unroll
+            for (u32 k = 0; k < kSlots; ++k) {
+                if (!ended && k <= kw) {
+                    if (!legal[k]) {
+                        if (!post) { ended = true; ip = next_emit; mode = kDone; }   // :323-327 -> emit_remainder
+                    } else {
+                        c.table[h[k]] = p[k] | check_bits(d[k]);        // :333 / :397
+                    }
+                }
+            }
+            if (!ended) {
+                bool hit = false;
+                if (kw < kSlots) {
+                    const u64 x0 = (static_cast<u64>(cb.v[0] ^ pb.v[0])) | (static_cast<u64>(cb.v[1] ^ pb.v[1]) << 32);
+                    const u64 x1 = (static_cast<u64>(cb.v[2] ^ pb.v[2])) | (static_cast<u64>(cb.v[3] ^ pb.v[3]) << 32);
+                    hit = static_cast<u32>(x0) == 0;                    // :334 / :398
+                    if (hit) {
+                        if (!post) op = lane_emit_literal16(c, op, next_emit, wp - next_emit, lb, lit_cap);   // :347
+                        base = wp;
+                        cand = wpos;
+                        if (x0) mlen = static_cast<u32>(__builtin_ctzll(x0)) >> 3;
+                        else if (x1) mlen = 8 + (static_cast<u32>(__builtin_ctzll(x1)) >> 3);
+                        else mlen = 16;
+                        if (mlen < 16) {
+                            ip = base + mlen;
+                            op = lane_emit_copy(c.dst, op, base - cand, mlen);     // :371-379
+                            mode = ip >= limit ? kDone : kPost;                    // :381-384
+                        } else {
+                            mode = kExtend;
+                        }
+                    }
+                }
+                if (!hit) {
+                    if (post) {                                         // the probe after a copy missed: next outer iteration
+                        next_emit = ip;
+                        ++ip;
+                        skip = 32;
+                        mode = kScan;
+                    } else {                                            // probes 0..min(kw, kSlots-1) missed  :339-340
+                        const u32 last = kw < kSlots ? kw : kSlots - 1;
+#pragma unroll
+                        for (u32 k = 0; k < kSlots; ++k)
+                            if (k == last) { ip = nx[k]; skip = sk[k]; }
+                    }
+                }
             }
         }
     }
@@ -334,11 +442,13 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     u32 per = env ? static_cast<u32>(atoi(env)) : (nblocks >= 16384 ? 64u : 16u);   // measured: scripts/sweep_layouts.py
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
     const u32 grid = (nblocks + per - 1) / per;
+    const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");           // test knob: never overshoot a short literal
+    const int lit_blind = !(ex && ex[0] == '1');
     if (variant == SNP_HASH_CRC32C)
         hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_CRC32C>, dim3(grid), dim3(per), 0, stream, in, in_off, in_len,
-                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables));
+                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind);
     else
         hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_MUL>, dim3(grid), dim3(per), 0, stream, in, in_off, in_len,
-                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables));
+                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind);
     return hipGetLastError();
 }
