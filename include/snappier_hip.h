@@ -81,6 +81,10 @@ snp_status snp_ctx_set_stream(snp_ctx* ctx, void* stream);
 const char* snp_ctx_last_error(const snp_ctx* ctx);
 /* Block until everything enqueued on the context's stream is done (for the *_batch entry points). */
 snp_status snp_ctx_synchronize(snp_ctx* ctx);
+/* Introspection for tests and tuning: how often this context took a code path since it was created.
+ * which: 0 = large single blocks decoded one wavefront per 64 KiB fragment (snp_try_decompress, tag index),
+ *        1 = large single blocks that fell back to the single-wavefront decoder (foreign / malformed streams). */
+uint64_t snp_ctx_counter(const snp_ctx* ctx, int which);
 const char* snp_status_string(int status);
 const char* snp_version(void);
 

@@ -5,13 +5,13 @@
 set -e
 cd "$(dirname "$0")/.."
 V=snappier_amd/variants
-SRC="snappier_amd/csrc/decompress.hip snappier_amd/csrc/decompress_lanes.hip snappier_amd/csrc/compress.hip snappier_amd/csrc/compress_lanes.hip snappier_amd/csrc/crc32c.hip snappier_amd/csrc/framing.hip snappier_amd/csrc/capi.hip"
+SRC="snappier_amd/csrc/decompress.hip snappier_amd/csrc/decompress_lanes.hip snappier_amd/csrc/tag_index.hip snappier_amd/csrc/compress.hip snappier_amd/csrc/compress_lanes.hip snappier_amd/csrc/crc32c.hip snappier_amd/csrc/framing.hip snappier_amd/csrc/capi.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fconstexpr-steps=100000000 -Wno-unused-function -Wl,-rpath,/opt/rocm/lib"
 declare -A VARIANTS=(
-  [passes0]="-DSNP_D_PASSES=0"
-  [passes1]="-DSNP_D_PASSES=1"
-  [passes2]="-DSNP_D_PASSES=2"
-  [passes3]="-DSNP_D_PASSES=3"
+  [slots1]="-DSNP_CL_SLOTS=1"
+  [slots2]="-DSNP_CL_SLOTS=2"
+  [slots3]="-DSNP_CL_SLOTS=3"
+  [slots4]="-DSNP_CL_SLOTS=4"
 )
 if [ "$1" = prof ]; then
   mkdir -p $V

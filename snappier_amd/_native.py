@@ -53,6 +53,7 @@ def lib() -> C.CDLL:
         "snp_ctx_set_stream": (i32, [vp, vp]),
         "snp_ctx_last_error": (C.c_char_p, [vp]),
         "snp_ctx_synchronize": (i32, [vp]),
+        "snp_ctx_counter": (u64, [vp, i32]),
         "snp_status_string": (C.c_char_p, [i32]),
         "snp_version": (C.c_char_p, []),
         "snp_max_compressed_length": (i64, [i64]),

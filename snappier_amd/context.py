@@ -36,6 +36,10 @@ class Context:
     def handle(self):
         return self._h
 
+    def counter(self, which: int) -> int:
+        """snp_ctx_counter: 0 = large blocks decoded per fragment, 1 = large blocks that fell back to one wavefront."""
+        return int(N.lib().snp_ctx_counter(self._h, which))
+
     def synchronize(self):
         st = N.lib().snp_ctx_synchronize(self._h)
         if st != N.OK:

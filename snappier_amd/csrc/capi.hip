@@ -14,7 +14,9 @@
 
 extern "C" {
 hipError_t snp_launch_decompress(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*,
-                                 const u8*, int, hipStream_t);
+                                 const u8*, int, hipStream_t, const u32*);
+u32 snp_tag_index_entries(u32, u32);
+hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
 hipError_t snp_launch_compress(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int,
                                hipStream_t);
 hipError_t snp_launch_decompress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*,
@@ -53,8 +55,10 @@ struct snp_ctx {
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
     int dec_lds = 0;         // dynamic LDS bytes per decode wavefront (occupancy throttle)
     int decode_layout = 0;   // 0/1 wave-per-block (default), 2 block-per-lane (SNAPPIER_HIP_DECODE=lanes)
+    u32 par_min = 4 * SNP_BLOCK_SIZE;   // single blocks at least this long are decoded one wavefront per 64 KiB fragment (0 = never)
     int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= 8192 fragments), 1 wave-per-fragment, 2 fragment-per-lane
     DevBuf in, out, meta, work, tables;
+    uint64_t counters[2] = {0, 0};   // snp_ctx_counter
     std::string err;
 
     // One launch of the decompressor over nblocks blocks, picking the layout (see decompress_lanes.hip).
@@ -66,7 +70,7 @@ struct snp_ctx {
             return check(snp_launch_decompress_lanes(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
                                                      chunk_type, stream), "decompress (lanes) launch");
         return check(snp_launch_decompress(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
-                                           chunk_type, fenced | ((dec_lds / 256) << 8), stream), "decompress launch");
+                                           chunk_type, fenced | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch");
     }
 
     // One launch of the compressor over nblocks fragments, picking the layout (see compress_lanes.hip).
@@ -136,9 +140,15 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     // SNAPPIER_HIP_COMPRESS=wave|lanes pins the compressor layout (default: by batch size)
     const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
     c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : 0;
+    // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
+    // fragments decoded in parallel (tag_index.hip); 0 = always one wavefront per block
+    const char* pm = getenv("SNAPPIER_HIP_PARALLEL_MIN");
+    if (pm) c->par_min = static_cast<u32>(strtoul(pm, nullptr, 10));
     *out_ctx = c;
     return SNP_OK;
 }
+
+uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 2) ? c->counters[which] : 0; }
 
 void snp_ctx_destroy(snp_ctx* c)
 {
@@ -422,12 +432,79 @@ snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* 
     u8* m = static_cast<u8*>(c->meta.p);
     bool ok = c->check(hipMemcpyAsync(m, &h, sizeof(h), hipMemcpyHostToDevice, s), "H2D meta");
     if (n) ok = ok && c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+
+    // A large block: one wavefront per 64 KiB output fragment, fragment starts from the tag index (tag_index.hip).
+    // Taken only for a clean preamble that fits the output; any fragment that does not come back OK (foreign streams
+    // whose copies cross fragments, malformed data) sends the whole block to the single-wavefront decoder below.
+    {
+        u32 expected = 0, hb = 0, shift = 0;
+        bool clean = false;
+        for (u32 i = 0; i < 5 && i < n; ++i) {                            // VarIntEncoding.Read.cs:38-79
+            const u32 ch = in[i], val = ch & 0x7fu;
+            if (val & ~(0xffffffffu >> shift)) break;
+            expected |= val << shift;
+            shift += 7;
+            hb = i + 1;
+            if (ch < 128) { clean = true; break; }
+        }
+        if (ok && clean && c->par_min && expected >= c->par_min && expected <= cap32 && n > hb && c->decode_layout != 2) {
+            const u32 nent = snp_tag_index_entries(static_cast<u32>(n), hb);
+            const u32 nf = (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
+            // fragment table: in_off, out_off (u64) ; in_len, out_cap, skip, out_len (u32) ; status (i32)
+            if (!c->ensure(c->work, static_cast<size_t>(nent) * 8 + 16, "hipMalloc(tag index)") ||
+                !c->ensure(c->tables, static_cast<size_t>(nf) * (8 * 2 + 4 * 5), "hipMalloc(fragment table)"))
+                return SNP_ERR_DEVICE;
+            u64* f_in_off = static_cast<u64*>(c->tables.p);
+            u64* f_out_off = f_in_off + nf;
+            u32* f_in_len = reinterpret_cast<u32*>(f_out_off + nf);
+            u32* f_out_cap = f_in_len + nf;
+            u32* f_skip = f_out_cap + nf;
+            u32* f_out_len = f_skip + nf;
+            i32* f_status = reinterpret_cast<i32*>(f_out_len + nf);
+            ok = c->check(snp_launch_tag_index(static_cast<const u8*>(c->in.p), static_cast<u32>(n), hb, expected,
+                                               static_cast<u64*>(c->work.p), f_in_off, f_in_len, f_out_off, f_out_cap, f_skip, s),
+                          "tag index");
+            ok = ok && c->check(snp_launch_decompress(static_cast<const u8*>(c->in.p), f_in_off, f_in_len, nf,
+                                                      static_cast<u8*>(c->out.p), f_out_off, f_out_cap, f_out_len, f_status,
+                                                      nullptr, c->fenced | ((c->dec_lds / 256) << 8), s, f_skip),
+                                "decompress fragments");
+            std::vector<i32> st(nf);
+            ok = ok && c->check(hipMemcpyAsync(st.data(), f_status, nf * 4ull, hipMemcpyDeviceToHost, s), "D2H status");
+            ok = ok && c->check(hipStreamSynchronize(s), "sync");
+            if (!ok) return SNP_ERR_DEVICE;
+            bool all_ok = true;
+            for (u32 f = 0; f < nf; ++f) all_ok = all_ok && st[f] == SNP_OK;
+            ++c->counters[all_ok ? 0 : 1];
+            if (!all_ok && getenv("SNAPPIER_HIP_DEBUG")) {
+                std::vector<u64> ent(nent), fo(nf);
+                std::vector<u32> sk(nf), il(nf);
+                (void)hipMemcpy(ent.data(), c->work.p, nent * 8ull, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(fo.data(), f_in_off, nf * 8ull, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(sk.data(), f_skip, nf * 4ull, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(il.data(), f_in_len, nf * 4ull, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[snappier] fragment decode fell back: n=%zu hb=%u expected=%u nent=%u last=(ip %u, op %u)\n", n, hb,
+                        expected, nent, static_cast<u32>(ent[nent - 1]), static_cast<u32>(ent[nent - 1] >> 32) & 0x7fffffffu);
+                for (u32 i = 0; i < nent && i < 12; ++i)
+                    fprintf(stderr, "   entry %u: ip %u op %u\n", i, static_cast<u32>(ent[i]), static_cast<u32>(ent[i] >> 32) & 0x7fffffffu);
+                u32 shown = 0;
+                for (u32 f = 0; f < nf && shown < 8; ++f)
+                    if (st[f] != SNP_OK) { fprintf(stderr, "   fragment %u: status %d in_off %llu in_len %u skip %u\n", f, st[f], (unsigned long long)fo[f], il[f], sk[f]); ++shown; }
+            }
+            if (all_ok) {
+                ok = c->check(hipMemcpyAsync(out, c->out.p, expected, hipMemcpyDeviceToHost, s), "D2H output") &&
+                     c->check(hipStreamSynchronize(s), "sync");
+                if (!ok) return SNP_ERR_DEVICE;
+                *written = expected;
+                return SNP_OK;
+            }
+        }
+    }
     ok = ok && c->check(snp_launch_decompress(static_cast<const u8*>(c->in.p), reinterpret_cast<u64*>(m + offsetof(Meta, in_off)),
                                               reinterpret_cast<u32*>(m + offsetof(Meta, in_len)), 1,
                                               static_cast<u8*>(c->out.p), reinterpret_cast<u64*>(m + offsetof(Meta, out_off)),
                                               reinterpret_cast<u32*>(m + offsetof(Meta, out_cap)),
                                               reinterpret_cast<u32*>(m + offsetof(Meta, out_len)),
-                                              reinterpret_cast<i32*>(m + offsetof(Meta, status)), nullptr, c->fenced, s),
+                                              reinterpret_cast<i32*>(m + offsetof(Meta, status)), nullptr, c->fenced, s, nullptr),
                         "decompress");
     ok = ok && c->check(hipMemcpyAsync(&h, m, sizeof(h), hipMemcpyDeviceToHost, s), "D2H meta");
     ok = ok && c->check(hipStreamSynchronize(s), "sync");

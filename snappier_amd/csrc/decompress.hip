@@ -150,22 +150,33 @@ __device__ unsigned long long g_dprof[16];
 #define DPROF_FLUSH
 #endif
 
-template <bool FENCED, int FRONT>   // FRONT: 0 serial loop only, 1 token-parallel batches, 2 batches feeding a 64-tag execution queue
+// FRAG = true decodes one 64 KiB output FRAGMENT of a larger block (see tag_index.hip): the wave starts at a tag
+// boundary at or before the fragment (`frag_skip[b]` output bytes early), parses the tags in between without producing
+// them, and stops when the fragment is full.  in_off/in_len = that tag start and the rest of the stream, out_off/out_cap
+// = the fragment.  A tag that straddles the fragment start or a copy that reaches back before it (legal Snappy, but
+// never produced by a compressor that works in independent 64 KiB fragments) ends with kIrregular; the caller then
+// decodes the whole block with one wavefront instead, which also owns the exact error semantics.
+constexpr i32 kIrregular = 99;
+
+template <bool FENCED, int FRONT, bool FRAG>   // FRONT: 0 serial loop only, 1 token-parallel batches, 2 batches feeding a 64-tag execution queue
 __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                         const u32* __restrict__ in_len, u32 nblocks, u8* out,
                                                         const u64* __restrict__ out_off,
                                                         const u32* __restrict__ out_cap, u32* __restrict__ out_len,
-                                                        i32* __restrict__ status, const u8* __restrict__ chunk_type)
+                                                        i32* __restrict__ status, const u8* __restrict__ chunk_type,
+                                                        const u32* __restrict__ frag_skip)
 {
+    static_assert(!FRAG || FRONT != 1, "fragment mode: serial loop or queued front end");
     const u32 b = blockIdx.x;
     if (b >= nblocks) return;
     const u32 lane = lane_id();
     const u8* src = in + in_off[b];
     const u32 n = bcast_first(in_len[b]);
-    u8* dst = out + out_off[b];
+    const u32 skip = FRAG ? bcast_first(frag_skip[b]) : 0u;             // output bytes parsed but not produced
+    u8* dst = out + out_off[b] - skip;                                  // output offsets below count from `skip` bytes early
     const u32 cap = bcast_first(out_cap[b]);
 
-    if (chunk_type && chunk_type[b] == 1) {     // framing: uncompressed chunk body  SnappyStreamDecompressor.cs:137-163
+    if (!FRAG && chunk_type && chunk_type[b] == 1) {     // framing: uncompressed chunk body  SnappyStreamDecompressor.cs:137-163
         const bool fits = n <= cap;
         if (fits) wave_copy(dst, src, n, lane);
         if (lane == 0) {
@@ -187,7 +198,9 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
     u32 ip = 0, op = 0, expected = 0;
 
     // ---- varint preamble  (VarIntEncoding.TryReadSlow  VarIntEncoding.Read.cs:38-79) -------------------------
-    {
+    if (FRAG) {
+        expected = skip + cap;                                          // no preamble: the fragment ends `cap` bytes after its start
+    } else {
         const u64 q = win_fetch(w, mis, lane);
         u32 shift = 0, result = 0;
         bool done = false;
@@ -383,12 +396,15 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                 const u32 total = read_lane(incl, 63);
                 const u32 ostart = op + incl - olen;
                 const bool is_lit = type == 0;
-                const bool bad = real && (is_lit ? (len == 0 || len + 16 > n - ip || body > n - ip - len - 16)
-                                                 : (off == 0 || off > ostart));
+                const bool live = real && (!FRAG || ostart >= skip);    // FRAG: tags before the fragment are only parsed
+                const bool bad = (live && (is_lit ? (len + 16 > n - ip || body > n - ip - len - 16)
+                                                  : (off == 0 || off > ostart - skip))) ||
+                                 (real && is_lit && len == 0) ||
+                                 (FRAG && real && ostart < skip && len > skip - ostart);   // straddles the fragment start
                 if (ballot64(bad) != 0ull || total + 16 > expected - op || consumed > n - ip) { parsing = false; continue; }
                 // literals longer than 64 bytes do not depend on anything: whole-wave memcpy right away
-                u64 big = ballot64(real && is_lit && len > 64);
-                const u64 enq = tags & ~big;
+                u64 big = ballot64(live && is_lit && len > 64);
+                const u64 enq = (FRAG ? ballot64(live) : tags) & ~big;
                 while (big) {
                     const u32 t = static_cast<u32>(__builtin_ctzll(big));
                     big &= big - 1;
@@ -480,6 +496,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
 
     // ---- tag loop  (SnappyDecompressor.cs:234-341) -----------------------------------------------------------
     while (st == SNP_OK && ip < n) {
+        if (FRAG && op >= expected) break;                              // fragment full: the next tag belongs to the next one
         DPROF_ADD(9, 1);                                                // tags taken by the serial loop
         const u64 q = win_fetch(w, ip + mis, lane);
         const u32 c = static_cast<u32>(q) & 0xffu;
@@ -497,6 +514,13 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
             const u32 avail = n - ip;
             const u32 take = len < avail ? static_cast<u32>(len) : avail;   // partial literal then stop  :290-297
             if (take > expected - op) { st = SNP_ERR_TOO_LONG; break; }     // Append  :570-573
+            if (FRAG && op < skip) {                                    // before the fragment: parse only
+                if (take > skip - op) { st = kIrregular; break; }
+                op += take;
+                ip += take;
+                if (take < len) break;
+                continue;
+            }
             if (take <= 64) {
                 if (lane < take) dst[op + lane] = src[ip + lane];
             } else {
@@ -509,7 +533,12 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
             u32 len, off;
             if (type == 1) { len = (hi6 & 7u) + 4; off = ((c >> 5) << 8) | trailer; }
             else { len = hi6 + 1; off = trailer; }
-            if (off == 0 || off > op) { st = SNP_ERR_BAD_OFFSET; break; }   // AppendFromSelf  :598-601
+            if (FRAG && op < skip) {                                    // before the fragment: parse only
+                if (len > skip - op) { st = kIrregular; break; }
+                op += len;
+                continue;
+            }
+            if (off == 0 || off > op - skip) { st = FRAG ? kIrregular : static_cast<i32>(SNP_ERR_BAD_OFFSET); break; }   // AppendFromSelf  :598-601
             if (len > expected - op) { st = SNP_ERR_TOO_LONG; break; }      // :603-606
             if (FENCED) {
                 const u32 src_end = op - off + (off < len ? off : len);
@@ -535,7 +564,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
     if (st == SNP_OK && op < expected) st = SNP_ERR_INCOMPLETE;        // Snappy.cs:178-181,229-232
 
     if (lane == 0) {
-        out_len[b] = st == SNP_OK ? op : 0u;
+        out_len[b] = st == SNP_OK ? op - skip : 0u;
         status[b] = st;
     }
 }
@@ -556,15 +585,27 @@ extern "C" int snp_debug_read_dprof(unsigned long long* out16, int reset)
 
 extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                             const u64* out_off, const u32* out_cap, u32* out_len, i32* status,
-                                            const u8* chunk_type, int mode, hipStream_t stream)
+                                            const u8* chunk_type, int mode, hipStream_t stream, const u32* frag_skip)
 {
     // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end), bit 2: batches without the execution queue;
     // bits 8..: dynamic LDS bytes / 256 requested per wavefront purely to cap how many blocks a CU decodes at once
     if (nblocks == 0) return hipSuccess;
     const unsigned lds_bytes = static_cast<unsigned>(mode >> 8) * 256u;
 #define SNP_LAUNCH_DEC(F, B)                                                                                        \
-    hipLaunchKernelGGL((k_decompress<F, B>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,   \
-                       nblocks, out, out_off, out_cap, out_len, status, chunk_type)
+    hipLaunchKernelGGL((k_decompress<F, B, false>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off,    \
+                       in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr)
+#define SNP_LAUNCH_FRAG(F, B)                                                                                       \
+    hipLaunchKernelGGL((k_decompress<F, B, true>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off,     \
+                       in_len, nblocks, out, out_off, out_cap, out_len, status, nullptr, frag_skip)
+    if (frag_skip) {                                    // fragments of one large block (tag_index.hip)
+        switch (mode & 7) {
+            case 0: case 4: SNP_LAUNCH_FRAG(false, 2); break;
+            case 1: case 5: SNP_LAUNCH_FRAG(true, 2); break;
+            case 2: case 6: SNP_LAUNCH_FRAG(false, 0); break;
+            default: SNP_LAUNCH_FRAG(true, 0); break;
+        }
+        return hipGetLastError();
+    }
     switch (mode & 7) {
         case 0: SNP_LAUNCH_DEC(false, 2); break;
         case 1: SNP_LAUNCH_DEC(true, 2); break;
@@ -574,5 +615,6 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
         default: SNP_LAUNCH_DEC(true, 1); break;
     }
 #undef SNP_LAUNCH_DEC
+#undef SNP_LAUNCH_FRAG
     return hipGetLastError();
 }

@@ -1,0 +1,146 @@
+"""Large single blocks through the host API (snp_try_decompress): a block of >= 256 KiB is split into 64 KiB output
+fragments with the tag index (csrc/tag_index.hip) and decoded one wavefront per fragment; anything a fragment cannot
+decode on its own (foreign streams whose copies cross fragments or whose tags straddle them, malformed data) must fall
+back to the single-wavefront decoder and give exactly the oracle's bytes / status.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import CORPUS, read_testdata
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import snappier_amd as S
+    from snappier_amd.errors import InvalidDataException
+    Snappy = S.Snappy
+
+
+def varint(v):
+    out = bytearray()
+    while v >= 128:
+        out.append((v & 0x7f) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def literal(data: bytes) -> bytes:
+    k = len(data) - 1
+    if k < 60:
+        return bytes([k << 2]) + data
+    nb = (k.bit_length() + 7) // 8
+    return bytes([(59 + nb) << 2]) + k.to_bytes(nb, "little") + data
+
+
+def copy2(off: int, ln: int) -> bytes:
+    return bytes([2 | ((ln - 1) << 2)]) + off.to_bytes(2, "little")
+
+
+def corpus_bytes(n: int) -> bytes:
+    files = [read_testdata(name) for name in CORPUS]
+    out = bytearray()
+    i = 0
+    while len(out) < n:
+        out += files[i % len(files)]
+        i += 1
+    return bytes(out[:n])
+
+
+def low_entropy_bytes(n: int) -> bytes:
+    return b"".join(datagen.low_entropy_block(7 + b, 65536).tobytes() for b in range((n + 65535) // 65536))[:n]
+
+
+@pytest.fixture(params=["default", "min1", "off"])
+def ctx(request, monkeypatch):
+    """default: parallel path from 256 KiB; min1: every block takes the parallel path; off: never."""
+    if request.param == "min1":
+        monkeypatch.setenv("SNAPPIER_HIP_PARALLEL_MIN", "1")
+    elif request.param == "off":
+        monkeypatch.setenv("SNAPPIER_HIP_PARALLEL_MIN", "0")
+    c = S.Context(0, O.HASH_CRC32C)
+    c.par_min = {"default": 262144, "min1": 1, "off": 0}[request.param]
+    return c
+
+
+@pytest.mark.parametrize("size", [1, 14, 65536, 65537, 131072, 262144, 262145, 1000000, 4 << 20])
+@pytest.mark.parametrize("kind", ["corpus", "low_entropy", "random"])
+def test_big_block_roundtrip_matches_oracle(ctx, kind, size):
+    if kind == "corpus":
+        data = corpus_bytes(size)
+    elif kind == "low_entropy":
+        data = low_entropy_bytes(size)
+    else:
+        data = np.random.default_rng(size).integers(0, 256, size, dtype=np.uint8).tobytes()
+    comp = Snappy.CompressToArray(data, ctx)
+    assert comp == O.compress(data, O.HASH_CRC32C)
+    assert Snappy.DecompressToArray(comp, ctx) == data
+    par_min = ctx.par_min
+    took_fragments = par_min != 0 and size >= par_min
+    assert (ctx.counter(0), ctx.counter(1)) == ((1, 0) if took_fragments else (0, 0))
+
+
+def test_foreign_streams_fall_back_and_match_oracle(ctx):
+    rng = np.random.default_rng(5)
+    head = rng.integers(0, 256, 65536, dtype=np.uint8).tobytes()
+    # (a) copies that reach back into the previous 64 KiB fragment
+    body = literal(head) + b"".join(copy2(60000 + (i % 5000), 64) for i in range(3200))
+    total = 65536 + 3200 * 64
+    s_a = varint(total) + body
+    # (b) a literal that straddles the first fragment boundary, then in-fragment copies
+    lit = rng.integers(0, 256, 65536 + 100, dtype=np.uint8).tobytes()
+    s_b = varint(len(lit) + 3200 * 64) + literal(lit) + b"".join(copy2(1 + (i % 90), 64) for i in range(3200))
+    # (c) a copy that straddles a fragment boundary (65536 - 32 bytes of literal, then 64-byte copies)
+    lit_c = rng.integers(0, 256, 65536 - 32, dtype=np.uint8).tobytes()
+    s_c = varint(len(lit_c) + 4000 * 64) + literal(lit_c) + b"".join(copy2(1000 + i, 64) for i in range(4000))
+    for name, stream in (("cross-fragment copies", s_a), ("straddling literal", s_b), ("straddling copy", s_c)):
+        ref = O.decompress(stream)
+        before = ctx.counter(1)
+        got = Snappy.DecompressToArray(stream, ctx)
+        assert got == ref, name
+        assert ctx.counter(1) == before + (1 if ctx.par_min else 0), name      # decoded by the fallback
+
+
+def test_malformed_big_blocks_report_the_oracle_status(ctx):
+    data = corpus_bytes(600000)
+    comp = bytearray(O.compress(data, O.HASH_CRC32C))
+    cases = []
+    cases.append(("truncated", bytes(comp[: len(comp) - 1000])))
+    longer = varint(len(data) + 5) + bytes(comp[len(varint(len(data))):])
+    cases.append(("declared too long", longer))
+    shorter = varint(len(data) - 5) + bytes(comp[len(varint(len(data))):])
+    cases.append(("declared too short", shorter))
+    # a copy with offset 0 spliced in after the first fragment's worth of compressed data
+    bad = bytes(comp[:40000]) + copy2(0, 8) + bytes(comp[40000:])
+    cases.append(("garbage in the middle", bad))
+    cases.append(("bad varint", b"\xff\xff\xff\xff\xff\x01" + bytes(comp[3:])))
+    for name, stream in cases:
+        want = O.decompress_status(stream)
+        assert want != 0, name
+        with pytest.raises(InvalidDataException) as ei:
+            Snappy.DecompressToArray(stream, ctx)
+        assert ei.value.status == want, name
+
+
+def test_big_block_output_too_small(ctx):
+    data = corpus_bytes(500000)
+    comp = O.compress(data, O.HASH_CRC32C)
+    out = np.empty(len(data) - 1, dtype=np.uint8)
+    ok, written = Snappy.TryDecompress(comp, out, ctx)
+    assert not ok and written == 0
+    out = np.empty(len(data) + 4096, dtype=np.uint8)
+    ok, written = Snappy.TryDecompress(comp, out, ctx)
+    assert ok and written == len(data) and out[:written].tobytes() == data
+
+
+def test_big_block_all_decoder_variants(monkeypatch):
+    data = corpus_bytes(3 << 20)
+    comp = O.compress(data, O.HASH_CRC32C)
+    for decode in ("queued", "serial", "batched"):
+        for fenced in ("0", "1"):
+            monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
+            monkeypatch.setenv("SNAPPIER_HIP_FENCED", fenced)
+            c = S.Context(0, O.HASH_CRC32C)
+            assert Snappy.DecompressToArray(comp, c) == data, (decode, fenced)
