@@ -21,6 +21,8 @@
 // LDS: the 16384 x u16 table = 32 KiB per wavefront, exactly 5 wavefronts per 160 KiB CU; no other LDS is used
 // (the probe-offset table lives in four VGPRs).  The hash for SNP_HASH_CRC32C is table-free: the CRC step is
 // GF(2)-linear, so bit i of it is parity(x & ROW[i]) (14 AND+popcount pairs; gfx950 has no CRC instruction).
+#include <cstdlib>
+
 #include "snp_device.h"
 
 namespace {
@@ -167,7 +169,10 @@ __device__ unsigned long long g_prof[16];
 #define PROF_FLUSH
 #endif
 
-template <int VARIANT>
+// STAGED = true first copies the fragment into LDS (64 KiB input + 32 KiB table = one fragment per CU): every probe,
+// candidate and extension load is then an LDS access instead of a global round trip.  For batches that cannot fill
+// the chip anyway (<= one fragment per CU) this is the fast layout; larger batches want five fragments per CU.
+template <int VARIANT, bool STAGED>
 __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                       const u32* __restrict__ in_len, u32 nblocks,
                                                       u8* __restrict__ out, const u64* __restrict__ out_off,
@@ -189,6 +194,12 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress(const u8* __restrict__ in
     if (n > SNP_BLOCK_SIZE) {
         if (lane == 0) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; }
         return;
+    }
+    __shared__ u8 s_in[STAGED ? SNP_BLOCK_SIZE : 16];
+    if (STAGED) {
+        wave_copy(s_in, src, n, lane);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // staged bytes are read by other lanes
+        src = s_in;
     }
 
     u32 op = 0;
@@ -432,11 +443,14 @@ extern "C" hipError_t snp_launch_compress(const u8* in, const u64* in_off, const
                                           int emit_varint, hipStream_t stream)
 {
     if (nblocks == 0) return hipSuccess;
-    if (variant == SNP_HASH_CRC32C)
-        hipLaunchKernelGGL(k_compress<SNP_HASH_CRC32C>, dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len,
-                           nblocks, out, out_off, out_len, status, emit_varint);
-    else
-        hipLaunchKernelGGL(k_compress<SNP_HASH_MUL>, dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len,
-                           nblocks, out, out_off, out_len, status, emit_varint);
+    // input staged in LDS while every fragment can have a CU to itself (SNAPPIER_HIP_STAGED=0/1 pins it)
+    const char* env = getenv("SNAPPIER_HIP_STAGED");
+    const bool staged = env ? env[0] == '1' : nblocks <= 256;
+#define SNP_LAUNCH_C(V, S)                                                                                          \
+    hipLaunchKernelGGL((k_compress<V, S>), dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, out, \
+                       out_off, out_len, status, emit_varint)
+    if (variant == SNP_HASH_CRC32C) { if (staged) SNP_LAUNCH_C(SNP_HASH_CRC32C, true); else SNP_LAUNCH_C(SNP_HASH_CRC32C, false); }
+    else { if (staged) SNP_LAUNCH_C(SNP_HASH_MUL, true); else SNP_LAUNCH_C(SNP_HASH_MUL, false); }
+#undef SNP_LAUNCH_C
     return hipGetLastError();
 }

@@ -1,16 +1,17 @@
-// crc32c.hip -- table-free, wave-parallel CRC-32C (Castagnoli, reflected 0x82F63B78) for the framing format.
+// crc32c.hip -- wave-parallel CRC-32C (Castagnoli, reflected 0x82F63B78) for the framing format.
 // Replaces Crc32CAlgorithm.Compute / ApplyMask (Snappier/Internal/Crc32CAlgorithm.cs:41-158), which uses the CPU's
 // crc32 instruction or 16 x 256-entry tables; gfx950 has neither a CRC instruction nor carry-less multiply.
 //
 // One wavefront per byte range.  CRC is GF(2)-linear: absorbing dword w into state s is s' = X32(s ^ w), where Xk =
 // "multiply by x^k mod P" (k reflected shift/xor steps).  So with dwords w_0..w_{N-1}
 //     state = XOR_t  X_{32(N-t)}(w_t)                       (the 0xFFFFFFFF init is XORed into the first 4 bytes)
-// The message is right-aligned on a 256-byte grid by (virtual) leading zero bytes, which change nothing.  Lane l
-// then owns dwords l, l+64, l+128, .. of the grid (coalesced 256 B wave loads) and runs a Horner recurrence
-//     acc_l = X2048(acc_l) ^ w
-// where X2048 is a constant GF(2) map applied as 32 {bit-extract, and-constant, xor} triples -- no table, no LDS.
-// A 6-level butterfly (left half times X_{32*2^k}, xor with the partner lane) folds the 64 accumulators, one X32
-// finishes.  Cost: ~100 VALU ops per 256 bytes per wave.
+// The message is right-aligned on a 1024-byte grid by (virtual) leading zero bytes, which change nothing.  Lane l
+// owns dwords 4l .. 4l+3 of every 1 KiB row (one coalesced 16-byte load per lane per row) and runs four Horner
+// recurrences   acc_j = X8192(acc_j) ^ w_j.   X8192 is a constant 32x32 GF(2) map, applied "sliced by 8": four
+// 256-entry tables in LDS (4 KiB per workgroup, copied from a compile-time constant), one lookup per accumulator
+// byte -- 4 LDS reads + ~10 VALU per dword instead of the 96 VALU of a bit-by-bit map, which is what bounded the
+// first version at 1.7 TB/s.  The four accumulators of a lane fold with three X32, the 64 lanes with a 6-level
+// butterfly (left half times X_{128*2^k}, xor with the partner lane), one X32 finishes.
 #include "snp_device.h"
 
 namespace {
@@ -51,6 +52,22 @@ __device__ __forceinline__ u32 xmul_bits(u32 v)
 template <int K>
 __device__ __forceinline__ u32 xmul(u32 v) { return xmul_bits<K, 0>(v); }
 
+// X8192 sliced by 8: kLut.t[k][b] = X8192(b << 8k)
+struct CrcLut {
+    u32 t[4][256];
+    constexpr CrcLut() : t{}
+    {
+        for (int k = 0; k < 4; ++k)
+            for (int b = 0; b < 256; ++b) {
+                u32 v = 0;
+                for (int bit = 0; bit < 8; ++bit)
+                    if (b & (1 << bit)) v ^= kXMap<8192>.col[8 * k + bit];
+                t[k][b] = v;
+            }
+    }
+};
+__device__ const CrcLut g_crc_lut{};
+
 __device__ __forceinline__ u32 xstep8(u32 v)
 {
 #pragma unroll
@@ -58,12 +75,17 @@ __device__ __forceinline__ u32 xstep8(u32 v)
     return v;
 }
 
-__global__ __launch_bounds__(SNP_WAVE) void k_crc32c(const u8* __restrict__ in, const u64* __restrict__ in_off,
-                                                    const u32* __restrict__ in_len, u32 nblocks, int masked,
-                                                    u32* __restrict__ out_crc, const u32* __restrict__ expect,
-                                                    i32* __restrict__ status)
+constexpr u32 kCrcWaves = 4;   // byte ranges per workgroup (they share the LDS table)
+
+__global__ __launch_bounds__(SNP_WAVE * kCrcWaves) void k_crc32c(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                                const u32* __restrict__ in_len, u32 nblocks, int masked,
+                                                                u32* __restrict__ out_crc, const u32* __restrict__ expect,
+                                                                i32* __restrict__ status)
 {
-    const u32 b = blockIdx.x;
+    __shared__ u32 T[4][256];
+    for (u32 e = threadIdx.x; e < 1024; e += SNP_WAVE * kCrcWaves) T[e >> 8][e & 255u] = g_crc_lut.t[e >> 8][e & 255u];
+    __syncthreads();
+    const u32 b = blockIdx.x * kCrcWaves + (threadIdx.x >> 6);
     if (b >= nblocks) return;
     const u32 lane = lane_id();
     const u8* src = in + in_off[b];
@@ -75,41 +97,56 @@ __global__ __launch_bounds__(SNP_WAVE) void k_crc32c(const u8* __restrict__ in, 
         for (u32 i = 0; i < n; ++i) s = xstep8(s ^ src[i]);
         crc = s ^ 0xffffffffu;
     } else {
-        const u32 padb = (256u - (n & 255u)) & 255u;                    // virtual leading zero bytes
-        const u32 rows = (n + padb) >> 8;
-        u32 acc = 0;
-        for (u32 i = 0; i < rows; ++i) {
-            const i32 rbyte = static_cast<i32>(i * 256u + lane * 4u) - static_cast<i32>(padb);   // offset of this lane's dword in src
-            u32 w;
+        const u32 padb = (1024u - (n & 1023u)) & 1023u;                 // virtual leading zero bytes
+        const u32 rows = (n + padb) >> 10;
+        u32 acc[4] = {0, 0, 0, 0};
+        // this lane's 16 bytes of row i start at src + i*1024 + lane*16 - padb
+        auto load_row = [&](u32 i, u32 (&w)[4]) {
+            const i32 rbyte = static_cast<i32>(i * 1024u + lane * 16u) - static_cast<i32>(padb);
             if (rbyte >= 4) {
-                w = ld32u(src + rbyte);
-            } else {                                                    // first rows only: leading pad and the init xor
-                w = 0;
+                const snp_u128_unaligned q = *reinterpret_cast<const snp_u128_unaligned*>(src + rbyte);
+                w[0] = q.v[0]; w[1] = q.v[1]; w[2] = q.v[2]; w[3] = q.v[3];
+            } else {                                                    // first row only: leading pad and the init xor
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const i32 bi = rbyte + j;
-                    if (bi >= 0) {
-                        u32 byte = src[bi];
-                        if (bi < 4) byte ^= 0xffu;                      // init 0xFFFFFFFF == first four bytes inverted
-                        w |= byte << (8 * j);
+                for (int d = 0; d < 4; ++d) {
+                    w[d] = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const i32 bi = rbyte + 4 * d + j;
+                        if (bi >= 0) {
+                            u32 byte = src[bi];
+                            if (bi < 4) byte ^= 0xffu;                  // init 0xFFFFFFFF == first four bytes inverted
+                            w[d] |= byte << (8 * j);
+                        }
                     }
                 }
             }
-            acc = xmul<2048>(acc) ^ w;
+        };
+        u32 cur[4], nxt[4] = {0, 0, 0, 0};
+        load_row(0, cur);
+        for (u32 i = 0; i < rows; ++i) {
+            if (i + 1 < rows) load_row(i + 1, nxt);                     // the next row is in flight while this one is absorbed
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const u32 a = acc[d];
+                acc[d] = T[0][a & 255u] ^ T[1][(a >> 8) & 255u] ^ T[2][(a >> 16) & 255u] ^ T[3][a >> 24] ^ cur[d];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) cur[d] = nxt[d];
         }
-        // fold the 64 lane accumulators: total = XOR_l X_{32(63-l)}(acc_l)
-        u32 v = acc;
-        if (!(lane & 1)) v = xmul<32>(v);
+        // fold: total = XOR_{l,d} X_{32(3-d) + 128(63-l)}(acc_{l,d}), then one X32
+        u32 v = xmul<32>(xmul<32>(xmul<32>(acc[0]) ^ acc[1]) ^ acc[2]) ^ acc[3];
+        if (!(lane & 1)) v = xmul<128>(v);
         v ^= __shfl_xor(v, 1, 64);
-        if (!(lane & 2)) v = xmul<64>(v);
+        if (!(lane & 2)) v = xmul<256>(v);
         v ^= __shfl_xor(v, 2, 64);
-        if (!(lane & 4)) v = xmul<128>(v);
+        if (!(lane & 4)) v = xmul<512>(v);
         v ^= __shfl_xor(v, 4, 64);
-        if (!(lane & 8)) v = xmul<256>(v);
+        if (!(lane & 8)) v = xmul<1024>(v);
         v ^= __shfl_xor(v, 8, 64);
-        if (!(lane & 16)) v = xmul<512>(v);
+        if (!(lane & 16)) v = xmul<2048>(v);
         v ^= __shfl_xor(v, 16, 64);
-        if (!(lane & 32)) v = xmul<1024>(v);
+        if (!(lane & 32)) v = xmul<4096>(v);
         v ^= __shfl_xor(v, 32, 64);
         crc = xmul<32>(v) ^ 0xffffffffu;                                // Crc32CAlgorithm.cs:48,153 final xor
     }
@@ -127,7 +164,7 @@ extern "C" hipError_t snp_launch_crc32c(const u8* in, const u64* in_off, const u
                                         u32* out_crc, const u32* expect, i32* status, hipStream_t stream)
 {
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_crc32c, dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, masked,
+    hipLaunchKernelGGL(k_crc32c, dim3((nblocks + kCrcWaves - 1) / kCrcWaves), dim3(SNP_WAVE * kCrcWaves), 0, stream, in, in_off, in_len, nblocks, masked,
                        out_crc, expect, status);
     return hipGetLastError();
 }
