@@ -1,0 +1,164 @@
+"""Differential fuzzing of the HIP codec against the oracle, every block compared (not sampled):
+  * structured random blocks (ragged lengths, repeats at random distances, runs, tiny alphabets, text) through both
+    compressor layouts and both hashes -> compressed bytes identical to the oracle's;
+  * the oracle's streams with random corruptions (byte flips, truncation, spliced tags, wrong preambles) through every
+    decoder front end -> per-block status identical to the oracle's, and identical bytes whenever it decodes.
+FUZZ_ROUNDS / FUZZ_BLOCKS scale it up (scripts/fuzz_parity.sh runs a long session on the GPU box).  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import read_testdata
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import snappier_amd as S
+    from snappier_amd import batch as SB
+
+ROUNDS = int(os.environ.get("FUZZ_ROUNDS", "2"))
+BLOCKS = int(os.environ.get("FUZZ_BLOCKS", "768"))
+THREADS = min(os.cpu_count() or 1, 64)
+EDGE_LENGTHS = [0, 1, 3, 4, 14, 15, 16, 17, 18, 19, 31, 32, 60, 61, 64, 65, 255, 256, 257, 4095, 4096, 16383, 16384, 16385,
+                32768, 65520, 65521, 65535, 65536]
+
+
+def make_block(rng: np.random.Generator, text: np.ndarray) -> np.ndarray:
+    n = int(rng.choice(EDGE_LENGTHS)) if rng.integers(0, 3) == 0 else int(rng.integers(0, 65537))
+    kind = int(rng.integers(0, 7))
+    if kind == 0:                                             # incompressible
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == 1:                                             # text window with mutations
+        s = int(rng.integers(0, len(text)))
+        b = np.resize(np.roll(text, -s), n).copy()
+        k = int(rng.integers(0, max(1, n // 20) + 1))
+        if n and k:
+            b[rng.integers(0, n, k)] = rng.integers(0, 256, k, dtype=np.uint8)
+        return b
+    if kind == 2:                                             # tiny alphabet: long matches, pattern copies
+        return rng.integers(0, int(rng.integers(1, 4)), n, dtype=np.uint8)
+    if kind == 3:                                             # runs of random length
+        out = np.empty(n, dtype=np.uint8)
+        pos = 0
+        while pos < n:
+            L = int(rng.integers(1, 1 << int(rng.integers(1, 11))))
+            out[pos:pos + L] = rng.integers(0, 256)
+            pos += L
+        return out
+    if kind == 4:                                             # random bytes with repeats copied from random distances
+        out = rng.integers(0, 256, n, dtype=np.uint8)
+        pos = 0
+        while pos < n:
+            pos += int(rng.integers(1, 200))
+            if pos >= n:
+                break
+            dist = int(rng.integers(1, min(pos, 65535) + 1))
+            L = min(int(rng.integers(4, 1 << int(rng.integers(3, 9)))), n - pos)
+            for i in range(0, L, dist):                       # forward copy semantics (overlap allowed)
+                out[pos + i: pos + min(i + dist, L)] = out[pos + i - dist: pos - dist + min(i + dist, L)]
+            pos += L
+        return out
+    if kind == 5:                                             # periodic pattern with a defect now and then
+        P = int(rng.integers(1, 70))
+        b = np.resize(rng.integers(0, 256, P, dtype=np.uint8), n).copy()
+        k = int(rng.integers(0, 6))
+        if n and k:
+            b[rng.integers(0, n, k)] ^= 0xFF
+        return b
+    a, c = make_block(rng, text), make_block(rng, text)       # two halves of different kinds
+    return np.concatenate([a[: len(a) // 2], c[: len(c) // 2]])[:65536]
+
+
+def batch_of(blocks):
+    lens = np.array([len(b) for b in blocks], dtype=np.int32)
+    off = np.zeros(len(blocks), dtype=np.int64)
+    off[1:] = np.cumsum(lens[:-1])
+    data = np.concatenate(blocks + [np.zeros(64, dtype=np.uint8)])
+    return data, off, lens
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("layout", ["wave", "lanes"])
+@pytest.mark.parametrize("variant", [O.HASH_CRC32C, O.HASH_MUL])
+def test_fuzz_compress_bytes_equal_oracle(layout, variant, monkeypatch):
+    monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout)
+    text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
+    cd = SB.BlockCodec(0, variant)
+    for r in range(ROUNDS):
+        rng = np.random.default_rng(1000 * r + 17 * variant + (layout == "lanes"))
+        blocks = [make_block(rng, text) for _ in range(BLOCKS)]
+        data, off, lens = batch_of(blocks)
+        ref, ref_off, ref_len, ref_st = O.compress_batch(data, off.astype(np.uint64), lens.astype(np.uint32), variant, THREADS)
+        out, out_off, out_len, status = cd.compress(dev(data), dev(off), dev(lens))
+        torch.cuda.synchronize()
+        out, out_off, out_len = out.cpu().numpy(), out_off.cpu().numpy(), out_len.cpu().numpy()
+        assert (status.cpu().numpy() == 0).all() and (ref_st == 0).all()
+        assert (out_len == ref_len).all(), f"round {r}: lengths differ at blocks {np.nonzero(out_len != ref_len)[0][:8]}"
+        for b in range(BLOCKS):
+            got = out[out_off[b]: out_off[b] + out_len[b]]
+            want = ref[int(ref_off[b]): int(ref_off[b]) + int(ref_len[b])]
+            assert np.array_equal(got, want), f"round {r} block {b} (len {lens[b]}) {layout} v{variant}"
+
+
+def corrupt(rng: np.random.Generator, z: np.ndarray) -> np.ndarray:
+    z = z.copy()
+    how = int(rng.integers(0, 7))
+    n = len(z)
+    if how == 0 or n < 8:
+        return z                                              # untouched
+    if how == 1:                                              # flip a few bytes anywhere
+        k = int(rng.integers(1, 4))
+        z[rng.integers(0, n, k)] ^= rng.integers(1, 256, k, dtype=np.uint8)
+        return z
+    if how == 2:                                              # truncate
+        return z[: int(rng.integers(0, n))]
+    if how == 3:                                              # flip inside the preamble / first tags
+        z[int(rng.integers(0, min(n, 6)))] ^= int(rng.integers(1, 256))
+        return z
+    if how == 4:                                              # splice a random tag somewhere
+        p = int(rng.integers(0, n))
+        tag = rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8)
+        return np.concatenate([z[:p], tag, z[p:]])
+    if how == 5:                                              # append garbage
+        return np.concatenate([z, rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)])
+    p = int(rng.integers(0, n))                               # zero a short range (offset 0 copies, long literals)
+    z[p: p + int(rng.integers(1, 9))] = 0
+    return z
+
+
+@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "lanes"])
+def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatch):
+    monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
+    text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    for r in range(ROUNDS):
+        rng = np.random.default_rng(777 + r)
+        blocks = [make_block(rng, text) for _ in range(BLOCKS)]
+        data, off, lens = batch_of(blocks)
+        comp, c_off, c_len, _ = O.compress_batch(data, off.astype(np.uint64), lens.astype(np.uint32), O.HASH_CRC32C, THREADS)
+        streams = [corrupt(rng, comp[int(c_off[b]): int(c_off[b]) + int(c_len[b])]) for b in range(BLOCKS)]
+        sdata, s_off, s_len = batch_of(streams)
+        caps = np.array([len(b) if rng.integers(0, 8) else max(0, len(b) - int(rng.integers(0, 3))) for b in blocks], dtype=np.int32)
+        caps = np.maximum(caps, 1)                            # a zero capacity is an argument error at the boundary
+        out_off = np.zeros(BLOCKS, dtype=np.int64)
+        out_off[1:] = np.cumsum(caps[:-1].astype(np.int64) + 64)
+        total = int(out_off[-1]) + int(caps[-1]) + 64
+        ref, ref_len, ref_st = O.decompress_batch(sdata, s_off.astype(np.uint64), s_len.astype(np.uint32), out_off.astype(np.uint64),
+                                                  caps.astype(np.uint32), total, THREADS)
+        out = torch.zeros(total, dtype=torch.uint8, device="cuda")
+        dlen, dst = cd.decompress(dev(sdata), dev(s_off), dev(s_len), out, dev(out_off), dev(caps))
+        torch.cuda.synchronize()
+        dlen, dst, out = dlen.cpu().numpy(), dst.cpu().numpy(), out.cpu().numpy()
+        bad = np.nonzero(dst != ref_st)[0]
+        assert bad.size == 0, f"round {r} {decode}: status differs at blocks {bad[:8]}: got {dst[bad[:8]]} want {ref_st[bad[:8]]}"
+        ok = np.nonzero(ref_st == 0)[0]
+        assert (dlen[ok] == ref_len[ok]).all()
+        for b in ok:
+            assert np.array_equal(out[out_off[b]: out_off[b] + dlen[b]], ref[out_off[b]: out_off[b] + ref_len[b]]), f"round {r} block {b}"
+        assert ok.size > BLOCKS // 10 and ok.size < BLOCKS    # the corruptions produce both outcomes
