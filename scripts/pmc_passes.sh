@@ -13,14 +13,14 @@ for set in "$@"; do
   timeout ${PMC_TIMEOUT:-120} rocprofv3 --pmc $set -d $d -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/pmc_$i.log 2>&1
   echo "== pass $i: $set (rc=$?)"
   python - "$d" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, re, sys, collections
 acc = collections.defaultdict(float)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_compress" in k or "k_decompress" in k or "k_crc" in k:
-            name = k.split("(")[0].split("::")[-1].split("<")[0]
-            acc[(name, r["Counter_Name"])] += float(r["Counter_Value"])
+        m = re.search(r"(k_(?:compress|decompress|crc|frame|tag)[a-z_0-9]*)", k)
+        if m:
+            acc[(m.group(1), r["Counter_Name"])] += float(r["Counter_Value"])
 for (k, c), v in sorted(acc.items()):
     print(f"   {k:20s} {c:32s} {v:.6g}")
 PY
