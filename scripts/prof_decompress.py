@@ -22,8 +22,9 @@ names = ["batches (queued: execution batches)", "tags in batches", "output bytes
          "tags round1", "tags round2", "pattern copies (coop)", "tags in serial loop"]
 for k, nme in enumerate(names):
     print(f"{nme:28s} {buf[k]/nb:12.1f} per block")
-tn = ["wait input window", "tag decode + next ptrs", "chain walk", "prefix sum + checks", "copies (all rounds)"]
+tn = ["wait input window", "parse (decode, chain, scan, enqueue)", "first pass", "extra pass", "serial finish"] if os.environ.get("SNAPPIER_HIP_DECODE", "queued") == "queued" else \
+     ["wait input window", "tag decode + next ptrs", "chain walk", "prefix sum + checks", "copies (all rounds)"]
 tot = sum(buf[10:15])
 for k, nme in enumerate(tn):
-    print(f"{nme:28s} {buf[10+k]/nb/282.0:10.0f} cycles/batch(~282 per block) {100*buf[10+k]/max(tot,1):5.1f}%")
+    print(f"{nme:38s} {buf[10+k]/nb:12.0f} cycles per block {100*buf[10+k]/max(tot,1):5.1f}%")
 print("rounds per batch", buf[3] / max(buf[0], 1), " tags per batch", buf[1] / max(buf[0], 1))

@@ -357,12 +357,14 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
         u32 head = 0, count = 0;                                        // input position | length + literal flag
         bool parsing = st == SNP_OK;
         u64 q_next = (parsing && ip + 72 <= n) ? ld64u(src + ip + lane) : 0ull;
+        DPROF_T0
         for (;;) {
             head = bcast_first(head);
             count = bcast_first(count);
             if (parsing && count <= 64 && ip + 72 <= n && op < expected) {
                 // ---- parse one 64-byte window (steps 1-3 of the batched path) ----
                 const u64 q = q_next;
+                DPROF_TIME(10);                                         // wait for the input window
                 const u32 c = static_cast<u32>(q) & 0xffu;
                 const u32 type = c & 3u;
                 const u32 hi6 = c >> 2;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                 count += static_cast<u32>(__builtin_popcountll(enq));
                 ip += consumed;
                 op += total;
+                DPROF_TIME(11);                                         // parse: decode, chain walk, prefix sum, enqueue
                 continue;
             }
             if (count == 0) break;
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
             DPROF_ADD(0, 1);                                            // execution batches
             DPROF_ADD(1, ne);                                           // tags executed
             DPROF_ADD(5, __builtin_popcountll(pend));                   // tags not ready in the first pass
+            DPROF_TIME(12);                                             // first pass
             // More lane-parallel passes: a pending copy may run as soon as its source no longer overlaps the output of
             // another pending tag (those bytes do not exist yet).  Most near copies read what an earlier pass just wrote;
             // each pass peels one level off every dependency chain.  Pattern copies go through the serial finish.
@@ -470,6 +474,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
 #endif
 #undef SNP_D_EXTRA_PASS
             DPROF_ADD(4, __builtin_popcountll(pend));                   // tags finished one by one
+            DPROF_TIME(13);                                             // extra pass(es)
             while (pend) {
                 const u32 f = static_cast<u32>(__builtin_ctzll(pend));
                 pend &= pend - 1;
@@ -488,7 +493,9 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
             asm volatile("" ::: "memory");
             head = (head + ne) & 127u;
             count -= ne;
+            DPROF_TIME(14);                                             // serial finish
         }
+        DPROF_FLUSH;
         w.wv = 0x80000000u;
     }
 
