@@ -8,10 +8,11 @@ V=snappier_amd/variants
 SRC="snappier_amd/csrc/decompress.hip snappier_amd/csrc/decompress_lanes.hip snappier_amd/csrc/tag_index.hip snappier_amd/csrc/compress.hip snappier_amd/csrc/compress_lanes.hip snappier_amd/csrc/crc32c.hip snappier_amd/csrc/framing.hip snappier_amd/csrc/capi.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fconstexpr-steps=100000000 -Wno-unused-function -Wl,-rpath,/opt/rocm/lib"
 declare -A VARIANTS=(
-  [slots1]="-DSNP_CL_SLOTS=1"
-  [slots2]="-DSNP_CL_SLOTS=2"
-  [slots3]="-DSNP_CL_SLOTS=3"
-  [slots4]="-DSNP_CL_SLOTS=4"
+  [stage0]="-DSNP_D_STAGE=0"
+  [stage2048]="-DSNP_D_STAGE=2048"
+  [stage2048w8]="-DSNP_D_STAGE=2048 -DSNP_D_WAVES=8"
+  [stage1024w8]="-DSNP_D_STAGE=1024 -DSNP_D_WAVES=8"
+  [stage3072w8]="-DSNP_D_STAGE=3072 -DSNP_D_WAVES=8"
 )
 if [ "$1" = prof ]; then
   mkdir -p $V

@@ -11,7 +11,7 @@ for layout in ("wave", "lanes64", "lanes32", "lanes16", "lanes8"):
     import snappier_amd as S
     from snappier_amd import batch as SB, datagen as SD
     cd = SB.BlockCodec(0, S.HASH_CRC32C)
-    for nb in (1024, 4096, 8192, 16384, 32768, 65536, 163840):
+    for nb in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 163840):
         raw = SD.html_like_blocks(html, 0, nb, "cuda")
         in_off, in_len = cd.uniform_layout(nb)
         out = torch.empty(nb * cd.comp_stride, dtype=torch.uint8, device="cuda")
