@@ -160,6 +160,17 @@ snp_status snp_frame_decode_chunks_device(snp_ctx* ctx, const uint8_t* d_in, con
                                           const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
                                           int32_t* status);
 
+/* Fully device-resident decode of a framed stream that arrives WITHOUT a chunk table (SnappyStreamDecompressor.cs:53-199):
+ * a device kernel walks the chunk headers (a serial chain -- each header gives the next, ~1 us per chunk), builds the
+ * chunk table in d_work, then all chunks are decoded and CRC-checked in one launch each.  max_chunks bounds the table
+ * (a stream with more data chunks, or one that decodes to more than cap bytes, ends with SNP_ERR_OUTPUT_TOO_SMALL);
+ * d_work must hold snp_frame_decode_workspace(max_chunks) bytes.  d_result (device, 2 x u64): [0] = bytes written
+ * (0 unless OK), [1] = status of the stream: the first failing chunk in stream order, else the error that ended the
+ * header walk, else SNP_OK.  Everything is enqueued on the context's stream. */
+uint64_t snp_frame_decode_workspace(uint32_t max_chunks);
+snp_status snp_frame_decode_device(snp_ctx* ctx, const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap,
+                                   uint32_t max_chunks, void* d_work, uint64_t* d_result);
+
 #ifdef __cplusplus
 }
 #endif

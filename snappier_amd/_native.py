@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
         "snp_frame_encode_workspace": (u64, [u64]),
         "snp_frame_encode_device": (i32, [vp, vp, u64, vp, u64, vp, vp]),
         "snp_frame_decode_chunks_device": (i32, [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp]),
+        "snp_frame_decode_workspace": (u64, [u32]),
+        "snp_frame_decode_device": (i32, [vp, vp, u64, vp, u64, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -105,3 +105,17 @@ class BlockCodec:
                                                     _p(out_len), _p(status))
         raise_for_status(st, self.ctx.handle)
         return out_len, status
+
+    def frame_decode(self, framed: torch.Tensor, nbytes: int, out: torch.Tensor, max_chunks: int, work: torch.Tensor | None = None):
+        """Framed stream without a chunk table, all on the device (snp_frame_decode_device): -> 2-element int64 tensor
+        (bytes written, status).  The chunk headers are walked by a device kernel (serial, ~1 us per chunk)."""
+        self._bind()
+        need = N.lib().snp_frame_decode_workspace(max_chunks)
+        if work is None:
+            work = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if work.numel() < need:
+            raise ValueError("frame_decode: work buffer too small")
+        result = torch.zeros(2, dtype=torch.int64, device=self.device)
+        st = N.lib().snp_frame_decode_device(self.ctx.handle, _p(framed), nbytes, _p(out), out.numel(), max_chunks, _p(work), _p(result))
+        raise_for_status(st, self.ctx.handle)
+        return result

@@ -29,6 +29,8 @@ hipError_t snp_launch_gather(const u8*, const u64*, const u32*, u8*, const u64*,
 hipError_t snp_launch_frame_chunks(u64, u32, u64, u64*, u32*, u64*, hipStream_t);
 hipError_t snp_launch_frame_plan(const u32*, const u32*, u32, u8*, u32*, u64*, u64*, hipStream_t);
 hipError_t snp_launch_frame_header_only(u8*, u64*, hipStream_t);
+hipError_t snp_launch_frame_scan(const u8*, u64, u64, u32, u8*, u64*, u32*, u32*, u64*, u32*, u64*, hipStream_t);
+hipError_t snp_launch_frame_result(const i32*, const u64*, u64*, hipStream_t);
 hipError_t snp_launch_frame_emit(const u8*, const u64*, const u8*, const u64*, const u8*, const u32*, const u32*,
                                  const u64*, u8*, u64, u32, hipStream_t);
 }
@@ -349,6 +351,40 @@ snp_status snp_frame_decode_chunks_device(snp_ctx* c, const uint8_t* d_in, const
     // CRC over the produced bytes, compared with the chunk's stored masked CRC  (SnappyStreamDecompressor.cs:117-131)
     ok = ok && c->check(snp_launch_crc32c(d_out, out_off, out_len, nchunks, 1, nullptr, chunk_crc, status, s),
                         "frame crc verify");
+    return ok ? SNP_OK : SNP_ERR_DEVICE;
+}
+
+// ---- framed stream without a chunk table: header walk on the device --------------------------------
+// workspace: 64-byte header {total, tail status, chunks} ; body_off, out_off (u64) ; body_len, crc, out_cap, out_len (u32) ;
+// status (i32) ; type (u8)
+uint64_t snp_frame_decode_workspace(uint32_t max_chunks)
+{
+    return 64 + align_up(static_cast<u64>(max_chunks) * (8 * 2 + 4 * 5 + 1), 16) + 16;
+}
+
+snp_status snp_frame_decode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap,
+                                   uint32_t max_chunks, void* d_work, uint64_t* d_result)
+{
+    if (!c || !d_work || !d_result || (n && !d_in) || (cap && !d_out)) return SNP_ERR_BAD_ARG;
+    if (!c->use_device()) return SNP_ERR_DEVICE;
+    hipStream_t s = c->stream;
+    u64* hdr = static_cast<u64*>(d_work);
+    u64* body_off = hdr + 8;
+    u64* out_off = body_off + max_chunks;
+    u32* body_len = reinterpret_cast<u32*>(out_off + max_chunks);
+    u32* crc = body_len + max_chunks;
+    u32* out_cap = crc + max_chunks;
+    u32* out_len = out_cap + max_chunks;
+    i32* status = reinterpret_cast<i32*>(out_len + max_chunks);
+    u8* type = reinterpret_cast<u8*>(status + max_chunks);
+    bool ok = c->check(snp_launch_frame_scan(d_in, n, cap, max_chunks, type, body_off, body_len, crc, out_off, out_cap, hdr, s),
+                       "frame scan");
+    if (ok && max_chunks && n) {                     // n == 0: no chunk, nothing to launch
+        const snp_status st = snp_frame_decode_chunks_device(c, d_in, type, body_off, body_len, crc, max_chunks, d_out, out_off,
+                                                             out_cap, out_len, status);
+        if (st != SNP_OK) return st;
+    }
+    ok = ok && c->check(snp_launch_frame_result(status, hdr, d_result, s), "frame result");
     return ok ? SNP_OK : SNP_ERR_DEVICE;
 }
 

@@ -117,6 +117,115 @@ __global__ __launch_bounds__(256) void k_frame_emit(const u8* __restrict__ raw, 
     block_copy(dst + o + SNP_CHUNK_HEADER_LEN, src, pl, tid);
 }
 
+
+// ---- device-side chunk-header walk (SnappyStreamDecompressor.ReadChunkHeader / Decompress  :53-199,215-289) -----
+// A framed stream carries no index: every header gives the position of the next one, so the walk is a serial chain of
+// ~64 KiB hops (one 16-byte load per chunk: type, 24-bit size, masked CRC and the first bytes of the block preamble).
+// One lane walks; the table it writes is exactly what the host walk in capi.hip produces.  Entries past the last data
+// chunk are filled as empty uncompressed chunks so that the decode and CRC launches can run over max_chunks without
+// knowing the count on the host.
+constexpr u32 kEmptyMaskedCrc = 0xa282ead8u;      // crc32c_mask(crc32c of no bytes = 0)
+
+__global__ __launch_bounds__(SNP_WAVE) void k_frame_scan(const u8* __restrict__ in, u64 n, u64 cap, u32 max_chunks,
+                                                        u8* __restrict__ type, u64* __restrict__ body_off,
+                                                        u32* __restrict__ body_len, u32* __restrict__ crc,
+                                                        u64* __restrict__ out_off, u32* __restrict__ out_cap,
+                                                        u64* __restrict__ hdr /* total, tail status, chunks */)
+{
+    __shared__ u64 s_total;
+    __shared__ u32 s_nc;
+    if (threadIdx.x == 0) {
+        u64 ip = 0, total = 0;
+        u32 nc = 0;
+        i32 tail = SNP_OK;
+        while (ip < n) {
+            if (n - ip < 4) { tail = SNP_ERR_TRUNCATED_STREAM; break; }
+            u32 b[4] = {0, 0, 0, 0};                                    // 16 bytes at ip (fewer at the very end)
+            if (n - ip >= 16) {
+                const snp_u128_unaligned q = *reinterpret_cast<const snp_u128_unaligned*>(in + ip);
+                b[0] = q.v[0]; b[1] = q.v[1]; b[2] = q.v[2]; b[3] = q.v[3];
+            } else {
+                for (u32 i = 0; i < n - ip; ++i) b[i >> 2] |= static_cast<u32>(in[ip + i]) << (8 * (i & 3));
+            }
+            const u32 t = b[0] & 0xffu;
+            const u32 size = b[0] >> 8;                                 // :64-65
+            ip += 4;
+            if (n - ip < size) { tail = SNP_ERR_TRUNCATED_STREAM; break; }
+            if (t <= 1) {
+                if (size < 4) { tail = SNP_ERR_TRUNCATED_STREAM; break; }
+                u32 dec = size - 4;
+                if (t == 0) {                                           // block preamble  VarIntEncoding.Read.cs:38-79
+                    const u64 pre = b[2] | (static_cast<u64>(b[3]) << 32);
+                    const u32 avail = size - 4 < 5 ? size - 4 : 5;
+                    u32 result = 0, shift = 0;
+                    bool done = false, bad = false;
+                    for (u32 i = 0; i < avail && !done && !bad; ++i) {
+                        const u32 c = static_cast<u32>(pre >> (8 * i)) & 0xffu;
+                        const u32 val = c & 0x7fu;
+                        if (val & ~(0xffffffffu >> shift)) { bad = true; break; }
+                        result |= val << shift;
+                        shift += 7;
+                        if (c < 128) done = true;
+                    }
+                    if (bad || !done || result > 0x7fffffffu) { tail = SNP_ERR_BAD_LENGTH; break; }
+                    dec = result;
+                }
+                if (nc == max_chunks) { tail = SNP_ERR_OUTPUT_TOO_SMALL; break; }   // chunk table full
+                type[nc] = static_cast<u8>(t);
+                body_off[nc] = ip + 4;
+                body_len[nc] = size - 4;
+                crc[nc] = b[1];                                         // ReadChunkCrc  :260-289
+                out_off[nc] = total;
+                out_cap[nc] = dec;
+                total += dec;
+                ++nc;
+            } else if (t < 0x80) {                                      // :182-185
+                tail = SNP_ERR_CHUNK_TYPE;
+                break;
+            }                                                           // 0x80..0xff skipped unvalidated  :187-196
+            ip += size;
+        }
+        if (total > cap) { tail = SNP_ERR_OUTPUT_TOO_SMALL; nc = 0; total = 0; }   // nothing is decoded
+        hdr[0] = total;
+        hdr[1] = static_cast<u64>(static_cast<u32>(tail));
+        hdr[2] = nc;
+        s_total = total;
+        s_nc = nc;
+    }
+    __syncthreads();
+    const u64 total = s_total;
+    for (u32 k = s_nc + threadIdx.x; k < max_chunks; k += SNP_WAVE) {
+        type[k] = 1;
+        body_off[k] = 0;
+        body_len[k] = 0;
+        crc[k] = kEmptyMaskedCrc;
+        out_off[k] = total;
+        out_cap[k] = 0;
+    }
+}
+
+// The stream's verdict: the first failing chunk in stream order (as the sequential reference would throw), else the
+// error that ended the header walk, else OK with the byte count.
+__global__ __launch_bounds__(256) void k_frame_result(const i32* __restrict__ status, const u64* __restrict__ hdr,
+                                                     u64* __restrict__ result)
+{
+    __shared__ u32 s_first;
+    if (threadIdx.x == 0) s_first = 0xffffffffu;
+    __syncthreads();
+    const u32 nc = static_cast<u32>(hdr[2]);
+    u32 first = 0xffffffffu;
+    for (u32 k = threadIdx.x; k < nc; k += 256)
+        if (status[k] != SNP_OK) { first = k; break; }
+    if (first != 0xffffffffu) atomicMin(&s_first, first);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        i32 st = static_cast<i32>(hdr[1]);
+        if (s_first != 0xffffffffu) st = status[s_first];
+        result[0] = st == SNP_OK ? hdr[0] : 0;
+        result[1] = static_cast<u64>(static_cast<u32>(st));
+    }
+}
+
 }  // namespace
 
 extern "C" hipError_t snp_launch_gather(const u8* src, const u64* src_off, const u32* seg_len, u8* dst,
@@ -157,5 +266,20 @@ extern "C" hipError_t snp_launch_frame_emit(const u8* raw, const u64* in_off, co
     if (nchunks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_frame_emit, dim3(nchunks), dim3(256), 0, stream, raw, in_off, comp, comp_off, type, payload,
                        crc, dst_off, dst, cap, nchunks);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t snp_launch_frame_scan(const u8* in, u64 n, u64 cap, u32 max_chunks, u8* type, u64* body_off,
+                                            u32* body_len, u32* crc, u64* out_off, u32* out_cap, u64* hdr,
+                                            hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(SNP_WAVE), 0, stream, in, n, cap, max_chunks, type, body_off, body_len,
+                       crc, out_off, out_cap, hdr);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t snp_launch_frame_result(const i32* status, const u64* hdr, u64* result, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_frame_result, dim3(1), dim3(256), 0, stream, status, hdr, result);
     return hipGetLastError();
 }

@@ -544,6 +544,73 @@ def test_frame_decode_chunks_device_resident(codec):
     assert dst[0] != 0 and (dst[1:] == 0).all()
 
 
+def test_frame_decode_device_walks_the_headers_itself(codec):
+    """snp_frame_decode_device: the framed stream arrives without a chunk table; a device kernel walks the headers
+    (skippable / padding / repeated stream-identifier chunks, raw and compressed chunks), decodes and CRC-checks every
+    chunk.  Bytes and the stream's status must equal the oracle's on good and broken streams."""
+    cd = codec[O.HASH_CRC32C]
+    raw = read_testdata("html") + read_testdata("fireworks.jpeg") + read_testdata("alice29.txt")
+    good = O.frame_encode(raw)
+
+    def chunk(t, body):
+        return bytes([t]) + len(body).to_bytes(3, "little") + body
+
+    # rebuild the stream chunk by chunk with extras in between
+    pos, pieces = 10, [good[:10]]
+    k = 0
+    while pos < len(good):
+        size = int.from_bytes(good[pos + 1:pos + 4], "little")
+        pieces.append(good[pos:pos + 4 + size])
+        if k % 3 == 0:
+            pieces.append(chunk(0xfe, b"\0" * (k + 1)))               # padding
+        if k % 4 == 1:
+            pieces.append(chunk(0x80 + k % 0x7e, b"skip me" * k))      # reserved skippable
+        if k == 2:
+            pieces.append(good[:10])                                   # a second stream identifier
+        pos += 4 + size
+        k += 1
+    spiced = b"".join(pieces)
+    empty_stream = good[:10]
+
+    def run(stream, cap=None, max_chunks=64):
+        fr = to_dev(np.frombuffer(stream, dtype=np.uint8)) if len(stream) else torch.empty(0, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(len(raw) + 64 if cap is None else cap, dtype=torch.uint8, device="cuda")
+        res = cd.frame_decode(fr, len(stream), out, max_chunks)
+        torch.cuda.synchronize()
+        written, status = (int(v) for v in res.cpu().tolist())
+        return out[:written].cpu().numpy().tobytes(), status
+
+    for name, stream in (("plain", good), ("with skippable chunks", spiced), ("header only", empty_stream), ("empty", b"")):
+        got, st = run(stream)
+        assert st == 0, name
+        assert_same(name, got, O.frame_decode(stream))
+
+    def oracle_status(stream):
+        try:
+            O.frame_decode(stream)
+            return 0
+        except O.OracleError as e:
+            return e.status
+
+    broken = []
+    b = bytearray(good); b[10 + 8 + 500] ^= 0x55; broken.append(("corrupt body", bytes(b)))
+    b = bytearray(good); b[10 + 4] ^= 1; broken.append(("crc flipped", bytes(b)))
+    broken.append(("truncated in a chunk", good[: len(good) - 100]))
+    broken.append(("truncated in a header", good[:10 + 2]))
+    broken.append(("unknown unskippable chunk", good[:10] + chunk(0x05, b"abc") + good[10:]))
+    b = bytearray(good); b[10 + 8] = 0xff; b[10 + 9] = 0xff; b[10 + 10] = 0xff; b[10 + 11] = 0xff; b[10 + 12] = 0x7f
+    broken.append(("bad block preamble", bytes(b)))
+    for name, stream in broken:
+        want = oracle_status(stream)
+        got, st = run(stream)
+        assert want != 0 and st == want and got == b"", (name, st, want)
+    # capacity / chunk-table limits
+    assert run(good, cap=len(raw) - 1)[1] == O.ERR_OUTPUT_TOO_SMALL
+    assert run(good, max_chunks=3)[1] == O.ERR_OUTPUT_TOO_SMALL
+    got, st = run(good, cap=len(raw), max_chunks=(len(raw) + 65535) // 65536)
+    assert st == 0 and got == raw
+
+
 # ------------------------------------------------------------------ full BASELINE size, size-independent properties
 
 @pytest.mark.timeout(1200)
