@@ -16,11 +16,11 @@
 //      5/6/7: read the entry, then write back the whole aligned 16 / 64 / 32 bytes around it (is a partially dirty
 //      sector a DRAM read-modify-write?)
 template <int ILP, int MODE>
-__global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint32_t nfrag, uint32_t probes, uint32_t* __restrict__ sink)
+__global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint32_t nfrag, uint32_t probes, uint32_t* __restrict__ sink, uint32_t span_log2)
 {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
     if (g >= nfrag) return;
-    uint32_t* t = tables + static_cast<uint64_t>(g) * 16384u;
+    uint32_t* t = tables + (static_cast<uint64_t>(g) << span_log2);      // span_log2 = 14: 64 KiB per lane (the kernel's layout)
     uint32_t st[ILP];
 #pragma unroll
     for (int k = 0; k < ILP; ++k) st[k] = g * 2654435761u + k * 40503u + 1u;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint
         uint32_t v[ILP], h[ILP];
 #pragma unroll
         for (int k = 0; k < ILP; ++k) {
-            h[k] = (st[k] * 0x1e35a7bdu) >> 18;
+            h[k] = (st[k] * 0x1e35a7bdu) >> (32 - span_log2);
             v[k] = MODE == 2 ? 0u : MODE == 4 ? __builtin_nontemporal_load(t + h[k]) : t[h[k]];
         }
 #pragma unroll
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+static uint32_t g_span_log2 = 14;
 template <int ILP, int MODE>
 static void run(uint32_t* tables, uint32_t* sink, uint32_t nfrag, uint32_t probes, const char* name)
 {
@@ -62,7 +63,7 @@ static void run(uint32_t* tables, uint32_t* sink, uint32_t nfrag, uint32_t probe
     CK(hipMemsetAsync(tables, 0, static_cast<size_t>(nfrag) * 65536, 0));
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(a, 0));
-        hipLaunchKernelGGL((k_walk<ILP, MODE>), dim3((nfrag + 63) / 64), dim3(64), 0, 0, tables, nfrag, probes, sink);
+        hipLaunchKernelGGL((k_walk<ILP, MODE>), dim3((nfrag + 63) / 64), dim3(64), 0, 0, tables, nfrag, probes, sink, g_span_log2);
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms = 0;
@@ -70,8 +71,8 @@ static void run(uint32_t* tables, uint32_t* sink, uint32_t nfrag, uint32_t probe
         if (rep == 1) {
             const double total = static_cast<double>(nfrag) * probes;
             printf("{\"case\": \"%s\", \"fragments\": %u, \"probes_per_fragment\": %u, \"ms\": %.3f, \"Gprobes_per_s\": %.2f, "
-                   "\"ms_for_10600_probes_x_163840\": %.1f}\n", name, nfrag, probes, ms, total / ms / 1e6,
-                   10600.0 * 163840.0 / (total / ms));
+                   "\"ms_for_10600_probes_x_163840\": %.1f, \"table_bytes_per_lane\": %u}\n", name, nfrag, probes, ms, total / ms / 1e6,
+                   10600.0 * 163840.0 / (total / ms), 4u << g_span_log2);
             fflush(stdout);
         }
     }
@@ -92,6 +93,14 @@ int main(int argc, char** argv)
         CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         printf("{\"case\": \"memset tables\", \"bytes\": %zu, \"ms\": %.3f}\n", static_cast<size_t>(nfrag) * 65536, ms);
+    }
+    if (argc > 3 && argv[3][0] == 's') {     // footprint sweep: same probes, smaller table span per lane (TLB reach / locality)
+        for (uint32_t sl = 14; sl >= 10; sl -= 2) {
+            g_span_log2 = sl;
+            run<1, 1>(tables, sink, nfrag, probes, "read+write, 1 chain per lane");
+            run<1, 0>(tables, sink, nfrag, probes, "read only, 1 chain per lane");
+        }
+        return 0;
     }
     if (argc > 3) {      // cache-resident sweep: few fragments, many chains
         run<1, 1>(tables, sink, nfrag, probes, "read+write, 1 chain per lane");
