@@ -16,11 +16,16 @@
 //      5/6/7: read the entry, then write back the whole aligned 16 / 64 / 32 bytes around it (is a partially dirty
 //      sector a DRAM read-modify-write?)
 template <int ILP, int MODE>
-__global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint32_t nfrag, uint32_t probes, uint32_t* __restrict__ sink, uint32_t span_log2)
+__global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint32_t nfrag, uint32_t probes, uint32_t* __restrict__ sink, uint32_t span_log2, uint32_t interleave)
 {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
     if (g >= nfrag) return;
     uint32_t* t = tables + (static_cast<uint64_t>(g) << span_log2);      // span_log2 = 14: 64 KiB per lane (the kernel's layout)
+    // interleave = 1: sector k of every lane's table is adjacent to sector k of its neighbours (entry h of lane g at
+    // ((h >> 4) * nfrag + g) * 16 + (h & 15)), so the traffic is uniform over the whole workspace at 64-byte granularity
+    auto at = [&](uint32_t h) -> uint32_t* {
+        return interleave ? tables + ((static_cast<uint64_t>(h >> 4) * nfrag + g) << 4) + (h & 15u) : t + h;
+    };
     uint32_t st[ILP];
 #pragma unroll
     for (int k = 0; k < ILP; ++k) st[k] = g * 2654435761u + k * 40503u + 1u;
@@ -29,11 +34,11 @@ __global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint
 #pragma unroll
         for (int k = 0; k < ILP; ++k) {
             h[k] = (st[k] * 0x1e35a7bdu) >> (32 - span_log2);
-            v[k] = MODE == 2 ? 0u : MODE == 4 ? __builtin_nontemporal_load(t + h[k]) : t[h[k]];
+            v[k] = MODE == 2 ? 0u : MODE == 4 ? __builtin_nontemporal_load(at(h[k])) : *at(h[k]);
         }
 #pragma unroll
         for (int k = 0; k < ILP; ++k) {
-            if (MODE == 1 || MODE == 2 || MODE == 4) t[h[k]] = i + k;
+            if (MODE == 1 || MODE == 2 || MODE == 4) *at(h[k]) = i + k;
             if (MODE == 3) __builtin_nontemporal_store(i + k, t + h[k]);
             if (MODE >= 5) {
                 constexpr uint32_t W = MODE == 5 ? 4 : MODE == 6 ? 16 : 8;     // dwords
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-static uint32_t g_span_log2 = 14;
+static uint32_t g_span_log2 = 14, g_interleave = 0;
 template <int ILP, int MODE>
 static void run(uint32_t* tables, uint32_t* sink, uint32_t nfrag, uint32_t probes, const char* name)
 {
@@ -63,7 +68,7 @@ static void run(uint32_t* tables, uint32_t* sink, uint32_t nfrag, uint32_t probe
     CK(hipMemsetAsync(tables, 0, static_cast<size_t>(nfrag) * 65536, 0));
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(a, 0));
-        hipLaunchKernelGGL((k_walk<ILP, MODE>), dim3((nfrag + 63) / 64), dim3(64), 0, 0, tables, nfrag, probes, sink, g_span_log2);
+        hipLaunchKernelGGL((k_walk<ILP, MODE>), dim3((nfrag + 63) / 64), dim3(64), 0, 0, tables, nfrag, probes, sink, g_span_log2, g_interleave);
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms = 0;
@@ -83,8 +88,21 @@ int main(int argc, char** argv)
     const uint32_t nfrag = argc > 1 ? atoi(argv[1]) : 163840;
     const uint32_t probes = argc > 2 ? atoi(argv[2]) : 4096;
     uint32_t *tables, *sink;
-    CK(hipMalloc(&tables, static_cast<size_t>(nfrag) * 65536));
     CK(hipMalloc(&sink, 64));
+    if (argc > 3 && argv[3][0] == 'p') {     // placement sweep: the same test with the tables allocated after k x 10 GiB of other buffers
+        g_interleave = argv[3][1] == 'i';
+        for (int k = 0; k < 26; ++k) {
+            void* pad;
+            if (k && hipMalloc(&pad, 10ull << 30) != hipSuccess) break;
+            CK(hipMalloc(&tables, static_cast<size_t>(nfrag) * 65536));
+            char name[96];
+            snprintf(name, sizeof name, "read+write after %d x 10 GiB at %p", k, (void*)tables);
+            run<1, 1>(tables, sink, nfrag, probes, name);
+            CK(hipFree(tables));
+        }
+        return 0;
+    }
+    CK(hipMalloc(&tables, static_cast<size_t>(nfrag) * 65536));
     {
         hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
         CK(hipMemsetAsync(tables, 0, static_cast<size_t>(nfrag) * 65536, 0));

@@ -24,6 +24,7 @@ hipError_t snp_launch_decompress_lanes(const u8*, const u64*, const u32*, u32, u
 hipError_t snp_launch_compress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, void*,
                                      hipStream_t);
 size_t snp_compress_lanes_workspace(u32);
+hipError_t snp_probe_tables(void*, u32, hipStream_t, float*);
 hipError_t snp_launch_crc32c(const u8*, const u64*, const u32*, u32, int, u32*, const u32*, i32*, hipStream_t);
 hipError_t snp_launch_gather(const u8*, const u64*, const u32*, u8*, const u64*, u32, hipStream_t);
 hipError_t snp_launch_frame_chunks(u64, u32, u64, u64*, u32*, u64*, hipStream_t);
@@ -57,6 +58,7 @@ struct snp_ctx {
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
     int dec_lds = 0;         // dynamic LDS bytes per decode wavefront (occupancy throttle)
     int decode_layout = 0;   // 0/1 wave-per-block (default), 2 block-per-lane (SNAPPIER_HIP_DECODE=lanes)
+    int table_tries = 4;     // candidates tried when a >= 1 GiB hash-table workspace is allocated (SNAPPIER_HIP_TABLE_TRIES)
     u32 par_min = 4 * SNP_BLOCK_SIZE;   // single blocks at least this long are decoded one wavefront per 64 KiB fragment (0 = never)
     int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= 8192 fragments), 1 wave-per-fragment, 2 fragment-per-lane
     DevBuf in, out, meta, work, tables;
@@ -83,7 +85,7 @@ struct snp_ctx {
         if (!lanes)
             return check(snp_launch_compress(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
                                              emit_varint, stream), "compress launch");
-        if (!ensure(tables, snp_compress_lanes_workspace(nblocks), "hipMalloc(hash tables)")) return false;
+        if (!ensure_tables(nblocks)) return false;
         return check(snp_launch_compress_lanes(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
                                                emit_varint, tables.p, stream), "compress (lanes) launch");
     }
@@ -103,6 +105,38 @@ struct snp_ctx {
         size_t want = bytes + bytes / 4 + 4096;
         if (!check(hipMalloc(&b.p, want), what)) return false;
         b.cap = want;
+        return true;
+    }
+    // The hash-table workspace of the lane compressor.  Large ones are placement-sensitive (compress_lanes.hip,
+    // snp_probe_tables): allocate up to `table_tries` candidates, keep the one HBM serves fastest.
+    bool ensure_tables(u32 nblocks)
+    {
+        const size_t bytes = snp_compress_lanes_workspace(nblocks);
+        if (bytes <= tables.cap) return true;
+        if (tables.p) (void)hipFree(tables.p);
+        tables = DevBuf{};
+        const size_t want = bytes + bytes / 4 + 4096;
+        int tries = (bytes >= (1ull << 30) && table_tries > 1) ? table_tries : 1;
+        size_t free_b = 0, total_b = 0;
+        if (tries > 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {   // the candidates coexist: stay within half of what is free
+            const size_t fit = free_b / 2 / want;
+            if (fit < static_cast<size_t>(tries)) tries = fit < 1 ? 1 : static_cast<int>(fit);
+        }
+        void* cand[16] = {nullptr};
+        float best_ms = 0;
+        int best = -1, got = 0;
+        for (int k = 0; k < tries && k < 16; ++k, ++got) {
+            if (hipMalloc(&cand[k], want) != hipSuccess) { (void)hipGetLastError(); cand[k] = nullptr; break; }
+            float ms = 0;
+            if (tries > 1 && snp_probe_tables(cand[k], nblocks, stream, &ms) != hipSuccess) ms = 1e30f;
+            if (best < 0 || ms < best_ms) { best = k; best_ms = ms; }
+            if (getenv("SNAPPIER_HIP_DEBUG")) fprintf(stderr, "[snappier] table workspace candidate %d at %p: probe %.2f ms\n", k, cand[k], ms);
+        }
+        for (int k = 0; k < got; ++k)
+            if (k != best && cand[k]) (void)hipFree(cand[k]);
+        if (best < 0) { err = "hipMalloc(hash tables): out of memory"; return false; }
+        tables.p = cand[best];
+        tables.cap = want;
         return true;
     }
     bool use_device() { return check(hipSetDevice(device), "hipSetDevice"); }
@@ -144,6 +178,8 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : 0;
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
     // fragments decoded in parallel (tag_index.hip); 0 = always one wavefront per block
+    const char* tt = getenv("SNAPPIER_HIP_TABLE_TRIES");
+    if (tt) c->table_tries = atoi(tt) < 1 ? 1 : atoi(tt) > 16 ? 16 : atoi(tt);
     const char* pm = getenv("SNAPPIER_HIP_PARALLEL_MIN");
     if (pm) c->par_min = static_cast<u32>(strtoul(pm, nullptr, 10));
     *out_ctx = c;

@@ -427,6 +427,48 @@ emit_remainder:
 
 }  // namespace
 
+// ---- workspace placement probe ---------------------------------------------------------------------------------
+// The kernel is bound by the rate at which HBM serves random 4-byte read-modify-writes spread over the whole table
+// workspace, and that rate depends on WHERE the driver placed the buffer: the same code measures 25-33 ms per 671 M
+// probes on differently placed 10 GiB buffers (four discrete levels; reads alone do not vary).  So when
+// a large workspace is allocated, capi.hip allocates a few candidates, times this probe (the table traffic of the
+// compressor and nothing else, a few ms) on each and keeps the fastest.
+namespace {
+__global__ __launch_bounds__(SNP_WAVE) void k_probe_tables(u32* __restrict__ tables, u32 nblocks, u32 probes)
+{
+    const u32 g = blockIdx.x * SNP_WAVE + threadIdx.x;
+    if (g >= nblocks) return;
+    u32* t = tables + static_cast<size_t>(g) * 16384u;
+    u32 st = g * 2654435761u + 1u;
+    for (u32 i = 0; i < probes; ++i) {
+        const u32 h = (st * 0x1e35a7bdu) >> 18;
+        const u32 v = t[h];
+        t[h] = i;
+        st = st * 1664525u + 1013904223u + v;
+    }
+    if (st == 0x12345678u) tables[0] = st;
+}
+}  // namespace
+
+extern "C" hipError_t snp_probe_tables(void* tables, u32 nblocks, hipStream_t stream, float* ms)
+{
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreate(&a);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&b);
+    if (e != hipSuccess) { (void)hipEventDestroy(a); return e; }
+    const u32 grid = (nblocks + SNP_WAVE - 1) / SNP_WAVE;
+    hipLaunchKernelGGL(k_probe_tables, dim3(grid), dim3(SNP_WAVE), 0, stream, static_cast<u32*>(tables), nblocks, 64u);   // warm
+    (void)hipEventRecord(a, stream);
+    hipLaunchKernelGGL(k_probe_tables, dim3(grid), dim3(SNP_WAVE), 0, stream, static_cast<u32*>(tables), nblocks, 768u);
+    (void)hipEventRecord(b, stream);
+    e = hipEventSynchronize(b);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return e;
+}
+
 extern "C" size_t snp_compress_lanes_workspace(u32 nblocks) { return static_cast<size_t>(nblocks) * 16384u * sizeof(u32); }
 
 extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
