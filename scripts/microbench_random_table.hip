@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint
             if (MODE == 1 || MODE == 2 || MODE == 4) *at(h[k]) = i + k;
             if (MODE == 3) __builtin_nontemporal_store(i + k, t + h[k]);
             if (MODE >= 5) {
-                constexpr uint32_t W = MODE == 5 ? 4 : MODE == 6 ? 16 : 8;     // dwords
+                constexpr uint32_t W = MODE == 5 ? 4 : MODE == 6 ? 16 : MODE == 8 ? 32 : 8;     // dwords
                 uint4* q = reinterpret_cast<uint4*>(t + (h[k] & ~(W - 1)));
                 uint4 x[W / 4];
 #pragma unroll
@@ -133,5 +133,7 @@ int main(int argc, char** argv)
     run<1, 5>(tables, sink, nfrag, probes, "read + write back aligned 16 B, 1 chain per lane");
     run<1, 7>(tables, sink, nfrag, probes, "read + write back aligned 32 B, 1 chain per lane");
     run<1, 6>(tables, sink, nfrag, probes, "read + write back aligned 64 B, 1 chain per lane");
+    run<1, 8>(tables, sink, nfrag, probes, "read + write back aligned 128 B, 1 chain per lane");
+    run<1, 1>(tables, sink, nfrag, probes, "read+write, 1 chain per lane (again)");
     return 0;
 }
