@@ -85,9 +85,18 @@ struct snp_ctx {
         if (!lanes)
             return check(snp_launch_compress(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
                                              emit_varint, stream), "compress launch");
-        if (!ensure_tables(nblocks)) return false;
-        return check(snp_launch_compress_lanes(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
-                                               emit_varint, tables.p, stream), "compress (lanes) launch");
+        // 64 KiB of table per fragment in flight: very large batches (millions of small blocks) go in slices, so the
+        // workspace stays <= 16 GiB; 262 144 fragments per launch still fill the chip many times over
+        constexpr u32 kSlice = 262144;
+        if (!ensure_tables(nblocks < kSlice ? nblocks : kSlice)) return false;
+        for (u32 first = 0; first < nblocks; first += kSlice) {
+            const u32 cnt = nblocks - first < kSlice ? nblocks - first : kSlice;
+            if (!check(snp_launch_compress_lanes(d_in, in_off + first, in_len + first, cnt, d_out, out_off + first,
+                                                 out_len + first, status + first, variant, emit_varint, tables.p, stream),
+                       "compress (lanes) launch"))
+                return false;
+        }
+        return true;
     }
 
     bool check(hipError_t e, const char* what)
