@@ -2,16 +2,15 @@
 // SnappyCompressor.CompressFragment (Snappier/Internal/SnappyCompressor.cs:174-415) for both TableEntry hashes.
 //
 // Why a second layout.  The reference parse is a serial chain: probe -> table lookup -> candidate compare -> insert,
-// ~4000 dependent steps per html-like fragment.  The wave-per-fragment kernel (compress.hip) keeps the table in LDS,
-// which caps a CU at 5 fragments in flight (5 x 32 KiB = all 160 KiB of LDS); every step is then a chain of
-// dependent memory/LDS round trips with nothing to overlap it, and the kernel measures ~1.5 us per step.
-// For LARGE batches the parallelism that matters is across fragments, so here every lane runs the serial parse of
-// its own fragment: 64 fragments per wavefront, tens of thousands of wavefronts' worth of independent memory
-// streams in flight.  The 16384-entry hash table of each fragment lives in an HBM workspace (u32 entries: position +
-// 16 check bits, 64 KiB per fragment,
-// zeroed by a memset before the launch -- HashTable.cs:52); LDS holds only the 4 x 256-entry table for the
-// SNP_HASH_CRC32C hash (the CRC step is GF(2)-linear, so it factors over the four input bytes; gfx950 has no
-// CRC instruction).  The kernel is bound by random 64-byte-sector traffic to the tables and candidates, not by
+// ~14 000 table accesses per html-like fragment.  The wave-per-fragment kernel (compress.hip) keeps the table in LDS,
+// which caps a CU at 5 fragments in flight (5 x 32 KiB = all 160 KiB of LDS), and a lone wavefront is bound by
+// instruction issue (~300 instructions per round).  For LARGE batches the parallelism that matters is across
+// fragments, so here every lane runs the serial parse of its own fragment: 64 fragments per wavefront, 163 840
+// independent memory streams in flight.  The 16384-entry hash table of each fragment lives in an HBM workspace (u32
+// entries: position + 16 check bits, 64 KiB per fragment, zeroed by a memset before the launch -- HashTable.cs:52);
+// LDS holds only the 4 x 256-entry table for the SNP_HASH_CRC32C hash (the CRC step is GF(2)-linear, so it factors
+// over the four input bytes; gfx950 has no CRC instruction).  The kernel is bound by the rate at which HBM serves
+// random 4-byte read-modify-writes to the tables (scripts/microbench_random_table.hip), not by
 // instruction issue.  Small batches keep using compress.hip (one wavefront per fragment is better there).
 #include <cstdlib>
 

@@ -16,8 +16,8 @@
 // Vector memory operations of one wave are issued and serviced in order, so a later load observes an earlier store
 // of the same wave (FENCED = true additionally drains vmcnt when a source range is younger than the last drain).
 //
-// BATCHED = true puts a token-parallel front end before that serial loop (the scalar unit -- one instruction per
-// cycle per CU -- is what bounds the serial loop: ~65 SALU instructions per tag):
+// FRONT = 1 puts a token-parallel front end before that serial loop (the scalar unit -- one instruction per cycle per
+// CU -- is what bounds the serial loop: ~65 SALU instructions per tag):
 //   1. all 64 lanes decode "the tag that would start at input byte ip + lane" (one unaligned 8-byte load each);
 //   2. the true tag starts are picked out by walking next-pointers (1, 2, 3, 4 hops precomputed with ds_bpermute),
 //      four tags per scalar step;
@@ -27,6 +27,9 @@
 //      (offset < length) and literals > 64 B are done cooperatively by the whole wave.
 //   Anything irregular (an error, a tag or literal running past the input, the last < 72 input bytes) leaves the
 //   batch untouched and falls through to the serial loop, which owns the exact error semantics.
+// FRONT = 2 (default) parses windows the same way but appends their tags to a queue in LDS and executes 64 tags at a
+// time, so every vector-memory instruction is issued with all its lanes busy (a 64-byte window holds only ~21 tags).
+// FRAG = true decodes one 64 KiB fragment of a larger block from a tag start found by tag_index.hip.
 #include "snp_device.h"
 
 namespace {
