@@ -102,6 +102,37 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (argc > 3 && argv[3][0] == 'a') {     // allocation flavours, several instances each
+        const size_t bytes = static_cast<size_t>(nfrag) * 65536;
+        for (int rep = 0; rep < 3; ++rep) {
+            for (int flavour = 0; flavour < 4; ++flavour) {
+                void* p = nullptr;
+                hipError_t e = hipSuccess;
+                const char* what = "";
+                if (flavour == 0) { e = hipMalloc(&p, bytes); what = "hipMalloc"; }
+                if (flavour == 1) { e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached); what = "hipExtMallocWithFlags(Uncached)"; }
+                if (flavour == 2) { e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained); what = "hipExtMallocWithFlags(Finegrained)"; }
+                if (flavour == 3) { e = hipMallocAsync(&p, bytes, 0); what = "hipMallocAsync"; }
+                if (e != hipSuccess) { printf("{\"case\": \"%s failed: %s\"}\n", what, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
+                char name[96];
+                snprintf(name, sizeof name, "read+write on %s #%d", what, rep);
+                run<1, 1>(static_cast<uint32_t*>(p), sink, nfrag, probes, name);
+                // keep it allocated so the next one lands elsewhere
+            }
+        }
+        return 0;
+    }
+    if (argc > 3 && argv[3][0] == 'o') {     // offset sweep inside ONE allocation: does the level depend on where the tables start?
+        const size_t step = (argc > 4 ? atol(argv[4]) : 1024) << 20, steps = argc > 5 ? atoi(argv[5]) : 17;
+        uint8_t* arena;
+        CK(hipMalloc(&arena, static_cast<size_t>(nfrag) * 65536 + step * steps));
+        for (size_t k = 0; k < steps; ++k) {
+            char name[96];
+            snprintf(name, sizeof name, "read+write at arena + %zu MiB", (k * step) >> 20);
+            run<1, 1>(reinterpret_cast<uint32_t*>(arena + k * step), sink, nfrag, probes, name);
+        }
+        return 0;
+    }
     CK(hipMalloc(&tables, static_cast<size_t>(nfrag) * 65536));
     {
         hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
