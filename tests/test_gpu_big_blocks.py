@@ -144,3 +144,52 @@ def test_big_block_all_decoder_variants(monkeypatch):
             monkeypatch.setenv("SNAPPIER_HIP_FENCED", fenced)
             c = S.Context(0, O.HASH_CRC32C)
             assert Snappy.DecompressToArray(comp, c) == data, (decode, fenced)
+
+
+def test_contexts_are_independent_across_threads():
+    """Snappy.* is re-entrant in the reference (a compressor per call, Snappy.cs:64,174,225); here: one context per
+    thread (default_context is thread-local).  Eight threads hammer the host API with different data at once."""
+    import threading
+    files = [read_testdata(name) for name in CORPUS]
+    errors = []
+
+    def work(t):
+        try:
+            rng = np.random.default_rng(t)
+            for i in range(12):
+                data = files[(t + i) % len(files)]
+                cut = int(rng.integers(1, len(data)))
+                data = data[:cut] if i % 3 else data
+                comp = Snappy.CompressToArray(data)                    # thread-local default context
+                assert comp == O.compress(data, O.HASH_CRC32C)
+                assert Snappy.DecompressToArray(comp) == data
+                framed = S.snappy.frame_encode(data)
+                assert S.snappy.frame_decode(framed) == data
+        except BaseException as e:                                     # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
+def test_work_follows_torch_streams():
+    """The batch API enqueues on torch's current stream: work issued on a side stream must be ordered with the tensors
+    produced and consumed there, without a device-wide sync."""
+    from snappier_amd import batch as SB, datagen as SD
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    html = read_testdata("html")
+    side = torch.cuda.Stream()
+    nb = 256
+    with torch.cuda.stream(side):
+        raw = SD.html_like_blocks(html, 5, nb, "cuda")
+        in_off, in_len = cd.uniform_layout(nb)
+        out, out_off, out_len, status = cd.compress(raw, in_off, in_len)
+        back = torch.empty_like(raw)
+        dlen, dst = cd.decompress(out, out_off, out_len, back, in_off, in_len)
+        same = torch.equal(back, raw)                                  # consumed on the same stream
+    side.synchronize()
+    assert same and int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0
