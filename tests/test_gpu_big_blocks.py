@@ -193,3 +193,31 @@ def test_work_follows_torch_streams():
         same = torch.equal(back, raw)                                  # consumed on the same stream
     side.synchronize()
     assert same and int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0
+
+
+def test_fuzz_corrupted_big_blocks_match_the_oracle(ctx):
+    """Random corruptions of large blocks through the host API: whatever path runs (fragments, fallback, single
+    wavefront), status and bytes are the oracle's."""
+    import test_gpu_fuzz as F
+    rng = np.random.default_rng(99)
+    kinds = (corpus_bytes, low_entropy_bytes)
+    ok_seen = bad_seen = 0
+    for i in range(int(__import__("os").environ.get("FUZZ_BIG", "36"))):
+        size = int(rng.integers(200000, 1500000))
+        data = kinds[i % 2](size)
+        z = np.frombuffer(O.compress(data, O.HASH_CRC32C), dtype=np.uint8)
+        stream = F.corrupt(rng, z).tobytes()
+        want = O.decompress_status(stream)
+        if want == 0:
+            assert Snappy.DecompressToArray(stream, ctx) == O.decompress(stream), i
+            ok_seen += 1
+        else:
+            cap = O.get_uncompressed_length(stream) if want not in (O.ERR_BAD_LENGTH,) else 0
+            try:
+                Snappy.DecompressToArray(stream, ctx)
+                got = 0
+            except InvalidDataException as e:
+                got = e.status
+            assert got == want, (i, got, want, cap)
+            bad_seen += 1
+    assert ok_seen and bad_seen
