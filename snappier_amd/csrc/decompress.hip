@@ -161,8 +161,17 @@ __device__ unsigned long long g_dprof[16];
 // decodes the whole block with one wavefront instead, which also owns the exact error semantics.
 constexpr i32 kIrregular = 99;
 
+#ifndef SNP_D_WAVES
+#define SNP_D_WAVES 0       // > 0: ask the compiler to fit this many wavefronts per SIMD (caps VGPRs at 512 / n)
+#endif
+#if SNP_D_WAVES
+#define SNP_D_OCC __attribute__((amdgpu_waves_per_eu(SNP_D_WAVES, SNP_D_WAVES)))
+#else
+#define SNP_D_OCC
+#endif
+
 template <bool FENCED, int FRONT, bool FRAG>   // FRONT: 0 serial loop only, 1 token-parallel batches, 2 batches feeding a 64-tag execution queue
-__global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ in, const u64* __restrict__ in_off,
+__global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                         const u32* __restrict__ in_len, u32 nblocks, u8* out,
                                                         const u64* __restrict__ out_off,
                                                         const u32* __restrict__ out_cap, u32* __restrict__ out_len,
@@ -372,14 +381,15 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                 const u32 type = c & 3u;
                 const u32 hi6 = c >> 2;
                 const u32 b1234 = static_cast<u32>(q >> 8);
-                const u32 extra = type == 0 ? (hi6 >= 60 ? hi6 - 59 : 0) : (type == 3 ? 4 : type);
-                const u32 trailer = extra >= 4 ? b1234 : (b1234 & ((1u << (8 * extra)) - 1u));
-                u32 len, off = 0;
-                if (type == 0) len = hi6 >= 60 ? trailer + 1 : hi6 + 1;
-                else if (type == 1) { len = (hi6 & 7u) + 4; off = ((c >> 5) << 8) | (b1234 & 0xffu); }
-                else { len = hi6 + 1; off = trailer; }
+                // (selects, not branches: all 64 lanes decode, and the three tag classes are evenly mixed)
+                const bool is_lit = type == 0;
+                const bool long_lit = is_lit && hi6 >= 60;
+                const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
+                const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
+                const u32 len = is_lit ? (long_lit ? trailer + 1 : hi6 + 1) : (type == 1 ? (hi6 & 7u) + 4 : hi6 + 1);
+                const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
                 const u32 body = lane + 1 + extra;
-                const u32 n1 = body + (type == 0 ? min(len, 0x40000000u) : 0);
+                const u32 n1 = body + (is_lit ? min(len, 0x40000000u) : 0u);
                 const u32 h2 = bperm(n1, n1);
                 const u32 n2 = n1 < 64 ? h2 : n1;
                 const u32 h3 = bperm(n1, n2);
@@ -400,11 +410,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress(const u8* __restrict__ 
                 const u32 incl = wave_inclusive_scan(olen);
                 const u32 total = read_lane(incl, 63);
                 const u32 ostart = op + incl - olen;
-                const bool is_lit = type == 0;
                 const bool live = real && (!FRAG || ostart >= skip);    // FRAG: tags before the fragment are only parsed
-                const bool bad = (live && (is_lit ? (len + 16 > n - ip || body > n - ip - len - 16)
-                                                  : (off == 0 || off > ostart - skip))) ||
-                                 (real && is_lit && len == 0) ||
+                // literal: 1 <= len, body + len + 16 <= n - ip (lane_copy over-reads 15 bytes); copy: 1 <= off <= bytes produced
+                const u32 room = n - ip - 16;                           // n - ip >= 72 here
+                const bool tag_ok = is_lit ? ((len - 1u) < room && body <= room - len) : ((off - 1u) < (ostart - skip));
+                const bool bad = (live && !tag_ok) || (FRAG && real && is_lit && len == 0) ||
                                  (FRAG && real && ostart < skip && len > skip - ostart);   // straddles the fragment start
                 if (ballot64(bad) != 0ull || total + 16 > expected - op || consumed > n - ip) { parsing = false; continue; }
                 // literals longer than 64 bytes do not depend on anything: whole-wave memcpy right away
