@@ -123,6 +123,12 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
     }
 }
 
+#ifndef SNP_D_WALK
+#define SNP_D_WALK 1        // queued mode, finding the tag starts of a window: 0 scalar walk (4 tags per step), 1 pointer doubling through LDS
+#endif
+// DS operations of one wavefront execute in order; this only stops the compiler from reordering or forwarding them.
+__device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory"); }
+
 #ifndef SNP_D_PASSES
 #define SNP_D_PASSES 1      // queued mode: extra lane-parallel passes over pending tags before the serial finish
 #endif
@@ -366,6 +372,7 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
     // in LDS, and copies are executed 64 tags at a time: the same ~10 memory instructions then serve three windows.
     if (FRONT == 2) {
         __shared__ u32 q_ostart[128], q_arg[128], q_meta[128];          // ring: output offset | copy offset or literal
+        __shared__ u8 s_reach[64];                                      // tag-start flags of the window being parsed
         u32 head = 0, count = 0;                                        // input position | length + literal flag
         bool parsing = st == SNP_OK;
         u64 q_next = (parsing && ip + 72 <= n) ? ld64u(src + ip + lane) : 0ull;
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
                 const u32 body = lane + 1 + extra;
                 const u32 n1 = body + (is_lit ? min(len, 0x40000000u) : 0u);
+#if SNP_D_WALK == 0
                 const u32 h2 = bperm(n1, n1);
                 const u32 n2 = n1 < 64 ? h2 : n1;
                 const u32 h3 = bperm(n1, n2);
@@ -404,6 +412,29 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                     pos = dq;
                 } while (pos < 64);
                 const u32 consumed = pos;
+#else
+                // Which positions are tag starts = which are reachable from position 0 along n1.  Pointer doubling: hop
+                // tables for 1, 2, 4, 8, 16, 32 tags (a value >= 64 leaves the window and sticks), then six rounds in which
+                // every position already reached marks the one 2^k tags further on -- through a 64-byte flag array in LDS,
+                // because a scatter needs the senders masked.  ~55 vector/LDS instructions per window whatever the number
+                // of tags, instead of a scalar walk of ~4 instructions per tag.
+                u32 hop = n1;
+                bool reached = lane == 0;
+                s_reach[lane] = lane == 0 ? 1 : 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    lanes_sync_lds();
+                    if (reached && hop < 64) s_reach[hop] = 1;
+                    lanes_sync_lds();
+                    reached = s_reach[lane] != 0;
+                    if (k < 5) {
+                        const u32 h = bperm(hop, hop);
+                        hop = hop < 64 ? h : hop;
+                    }
+                }
+                const u64 tags = ballot64(reached);
+                const u32 consumed = read_lane(n1, 63u - static_cast<u32>(__builtin_clzll(tags)));   // where the last tag of the window ends
+#endif
                 if (consumed <= n - ip && ip + consumed + 72 <= n) q_next = ld64u(src + ip + consumed + lane);
                 const bool real = (tags >> lane) & 1ull;
                 const u32 olen = real ? len : 0u;
