@@ -189,10 +189,10 @@ def main():
             # What bounds the lane compressor is not U + C but the random 4-byte read-modify-writes of its hash tables
             # (DESIGN.md 4.3).  Rates: scripts/microbench_random_table.hip on this GPU model (profiles/
             # r01d_microbench_random_table.jsonl: 20.26 G read+write probes/s, 23.57 G write-only inserts/s); counts: the
-            # reference parse makes 9815 probes + 4193 post-copy inserts per fragment of this workload (counted on the CPU
+            # reference parse makes 9928 probes + 4228 post-copy inserts per fragment of this workload (first 256 blocks, counted on the CPU
             # with the oracle).  floor = table traffic alone, nothing else in the kernel.
-            floor_ms = nb * (9815 / 20.26e9 + 4193 / 23.57e9) * 1e3
-            r_c["random_access_floor"] = {"table_probes_per_fragment": 9815, "table_inserts_per_fragment": 4193,
+            floor_ms = nb * (9928 / 20.26e9 + 4228 / 23.57e9) * 1e3
+            r_c["random_access_floor"] = {"table_probes_per_fragment": 9928, "table_inserts_per_fragment": 4228,
                                           "floor_ms": round(floor_ms, 1), "frac_of_floor": round(floor_ms / ms_c, 3)}
         line = {
             "metric": "uncompressed GB/s block compress+decompress, 64 KiB blocks",
