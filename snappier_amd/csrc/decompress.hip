@@ -112,14 +112,17 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
             if (len > 48) *reinterpret_cast<snp_u128_unaligned*>(d + 32) = *reinterpret_cast<const snp_u128_unaligned*>(s + 32);
         }
     } else {
+        // 8 / 4 / 2 / 1-byte pieces, each cut from the front of what is left of the 16 bytes (a running "shift")
+        const bool c8 = (len & 8u) != 0, c4 = (len & 4u) != 0, c2 = (len & 2u) != 0;
+        const u32 a0 = c8 ? p0.v[2] : p0.v[0];                          // after the 8-byte piece
+        const u32 a1 = c8 ? p0.v[3] : p0.v[1];
+        const u32 b0 = c4 ? a1 : a0;                                    // after the 4-byte piece
+        const u32 c0 = c2 ? b0 >> 16 : b0;                              // after the 2-byte piece
         const u32 o4 = len & 8u, o2 = len & 12u, o1 = len & 14u;
-        const u32 w4 = o4 ? p0.v[2] : p0.v[0];
-        const u32 w2 = (o2 & 8u) ? ((o2 & 4u) ? p0.v[3] : p0.v[2]) : ((o2 & 4u) ? p0.v[1] : p0.v[0]);
-        const u32 w1 = ((o1 & 8u) ? ((o1 & 4u) ? p0.v[3] : p0.v[2]) : ((o1 & 4u) ? p0.v[1] : p0.v[0])) >> ((o1 & 2u) * 8u);
-        if (len & 8u) reinterpret_cast<snp_u64_unaligned*>(d)->v = p0.v[0] | (static_cast<u64>(p0.v[1]) << 32);
-        if (len & 4u) st32u(d + o4, w4);
-        if (len & 2u) reinterpret_cast<snp_u16_unaligned*>(d + o2)->v = static_cast<u16>(w2);
-        if (len & 1u) d[o1] = static_cast<u8>(w1);
+        if (c8) reinterpret_cast<snp_u64_unaligned*>(d)->v = p0.v[0] | (static_cast<u64>(p0.v[1]) << 32);
+        if (c4) st32u(d + o4, a0);
+        if (c2) reinterpret_cast<snp_u16_unaligned*>(d + o2)->v = static_cast<u16>(b0);
+        if (len & 1u) d[o1] = static_cast<u8>(c0);
     }
 }
 
