@@ -503,7 +503,7 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                     const u32 f = static_cast<u32>(__builtin_ctzll(it));                                             \
                     it &= it - 1;                                                                                    \
                     const u32 f_o = read_lane(e_ostart, f), f_end = f_o + read_lane(e_len, f);                       \
-                    blocked = blocked || (lane > f && s_lo < f_end && s_hi > f_o);                                   \
+                    blocked = blocked || (s_lo < f_end && s_hi > f_o);   /* f >= lane cannot overlap: s_hi <= own ostart */ \
                 }                                                                                                    \
                 const bool ready2 = ((pend >> lane) & 1ull) && !blocked;                                             \
                 if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
