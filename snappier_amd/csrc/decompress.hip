@@ -396,7 +396,7 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 const bool long_lit = is_lit && hi6 >= 60;
                 const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
                 const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
-                const u32 len = is_lit ? (long_lit ? trailer + 1 : hi6 + 1) : (type == 1 ? (hi6 & 7u) + 4 : hi6 + 1);
+                const u32 len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);   // literal / copy-1 / copy-2,4
                 const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
                 const u32 body = lane + 1 + extra;
                 const u32 n1 = body + (is_lit ? min(len, 0x40000000u) : 0u);
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
             // More lane-parallel passes: a pending copy may run as soon as its source no longer overlaps the output of
             // another pending tag (those bytes do not exist yet).  Most near copies read what an earlier pass just wrote;
             // each pass peels one level off every dependency chain.  Pattern copies go through the serial finish.
-            const u32 s_lo = e_ostart - e_off, s_hi = s_lo + e_len;
+            const u32 s_lo = e_ostart - e_off, s_hi = s_lo + e_len, e_end = e_ostart + e_len;
 #define SNP_D_EXTRA_PASS                                                                                             \
             if (pend & (pend - 1)) {                                                                                 \
                 bool blocked = e_off < e_len;                                                                        \
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 while (it) {                                                                                         \
                     const u32 f = static_cast<u32>(__builtin_ctzll(it));                                             \
                     it &= it - 1;                                                                                    \
-                    const u32 f_o = read_lane(e_ostart, f), f_end = f_o + read_lane(e_len, f);                       \
+                    const u32 f_o = read_lane(e_ostart, f), f_end = read_lane(e_end, f);                             \
                     blocked = blocked || (s_lo < f_end && s_hi > f_o);   /* f >= lane cannot overlap: s_hi <= own ostart */ \
                 }                                                                                                    \
                 const bool ready2 = ((pend >> lane) & 1ull) && !blocked;                                             \
