@@ -417,20 +417,21 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 const u32 consumed = pos;
 #else
                 // Which positions are tag starts = which are reachable from position 0 along n1.  Pointer doubling: hop
-                // tables for 1, 2, 4, 8, 16, 32 tags (a value >= 64 leaves the window and sticks), then six rounds in which
+                // tables for 1, 2, 4, 8, 16 tags (a value >= 64 leaves the window and sticks), then five rounds in which
                 // every position already reached marks the one 2^k tags further on -- through a 64-byte flag array in LDS,
-                // because a scatter needs the senders masked.  ~55 vector/LDS instructions per window whatever the number
-                // of tags, instead of a scalar walk of ~4 instructions per tag.
+                // because a scatter needs the senders masked.  Five rounds reach every tag: a tag is at least two bytes
+                // long, so a 64-byte window starts at most 32 of them (hops 0..31).  ~60 vector/LDS instructions per
+                // window whatever the number of tags, instead of a scalar walk of ~4 instructions per tag.
                 u32 hop = n1;
                 bool reached = lane == 0;
                 s_reach[lane] = lane == 0 ? 1 : 0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
+                for (int k = 0; k < 5; ++k) {
                     lanes_sync_lds();
                     if (reached && hop < 64) s_reach[hop] = 1;
                     lanes_sync_lds();
                     reached = s_reach[lane] != 0;
-                    if (k < 5) {
+                    if (k < 4) {
                         const u32 h = bperm(hop, hop);
                         hop = hop < 64 ? h : hop;
                     }
