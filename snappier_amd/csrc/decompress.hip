@@ -383,7 +383,7 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
         for (;;) {
             head = bcast_first(head);
             count = bcast_first(count);
-            if (parsing && count <= 64 && ip + 72 <= n && op < expected) {
+            while (parsing && count <= 64 && ip + 72 <= n && op < expected) {
                 // ---- parse one 64-byte window (steps 1-3 of the batched path) ----
                 const u64 q = q_next;
                 DPROF_TIME(10);                                         // wait for the input window
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 count += static_cast<u32>(__builtin_popcountll(enq));
                 ip += consumed;
                 op += total;
+                count = bcast_first(count);
                 DPROF_TIME(11);                                         // parse: decode, chain walk, prefix sum, enqueue
-                continue;
             }
             if (count == 0) break;
             // ---- execute up to 64 queued tags: one lane-parallel pass, then dependent tags one by one ----
