@@ -441,7 +441,11 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 const u32 consumed = read_lane(n1, 63u - static_cast<u32>(__builtin_clzll(tags)));   // where the last tag of the window ends
 #endif
                 if (consumed <= n - ip && ip + consumed + 72 <= n) q_next = ld64u(src + ip + consumed + lane);
+#if SNP_D_WALK == 0
                 const bool real = (tags >> lane) & 1ull;
+#else
+                const bool real = reached;
+#endif
                 const u32 olen = real ? len : 0u;
                 const u32 incl = wave_inclusive_scan(olen);
                 const u32 total = read_lane(incl, 63);
@@ -449,9 +453,12 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 const bool live = real && (!FRAG || ostart >= skip);    // FRAG: tags before the fragment are only parsed
                 // literal: 1 <= len, body + len + 16 <= n - ip (lane_copy over-reads 15 bytes); copy: 1 <= off <= bytes produced
                 const u32 room = n - ip - 16;                           // n - ip >= 72 here
-                const bool tag_ok = is_lit ? ((len - 1u) < room && body <= room - len) : ((off - 1u) < (ostart - skip));
-                const bool bad = (live && !tag_ok) || (FRAG && real && is_lit && len == 0) ||
-                                 (FRAG && real && ostart < skip && len > skip - ostart);   // straddles the fragment start
+                // (bitwise, not short-circuit: these are lane masks, and branches over a handful of compares cost more)
+                const bool lit_ok = ((len - 1u) < room) & (body <= room - len);
+                const bool copy_ok = (off - 1u) < (ostart - skip);
+                const bool tag_ok = (is_lit & lit_ok) | (!is_lit & copy_ok);
+                bool bad = live & !tag_ok;
+                if (FRAG) bad = bad | (real & is_lit & (len == 0)) | (real & (ostart < skip) & (len > skip - ostart));   // straddles the fragment start
                 if (ballot64(bad) != 0ull || total + 16 > expected - op || consumed > n - ip) { parsing = false; continue; }
                 // literals longer than 64 bytes do not depend on anything: whole-wave memcpy right away
                 u64 big = ballot64(live && is_lit && len > 64);
