@@ -423,19 +423,18 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 // because a scatter needs the senders masked.  Five rounds reach every tag: a tag is at least two bytes
                 // long, so a 64-byte window starts at most 32 of them (hops 0..31).  ~60 vector/LDS instructions per
                 // window whatever the number of tags, instead of a scalar walk of ~4 instructions per tag.
+                // (round 0 needs no scatter: position 0 reaches exactly n1 of lane 0)
                 u32 hop = n1;
-                bool reached = lane == 0;
-                s_reach[lane] = lane == 0 ? 1 : 0;
+                bool reached = lane == 0 || lane == read_lane(n1, 0);
+                s_reach[lane] = reached ? 1 : 0;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
+                for (int k = 1; k < 5; ++k) {
+                    const u32 h = bperm(hop, hop);                      // hop table for 2^k tags
+                    hop = hop < 64 ? h : hop;
                     lanes_sync_lds();
                     if (reached && hop < 64) s_reach[hop] = 1;
                     lanes_sync_lds();
                     reached = s_reach[lane] != 0;
-                    if (k < 4) {
-                        const u32 h = bperm(hop, hop);
-                        hop = hop < 64 ? h : hop;
-                    }
                 }
                 const u64 tags = ballot64(reached);
                 const u32 consumed = read_lane(n1, 63u - static_cast<u32>(__builtin_clzll(tags)));   // where the last tag of the window ends
