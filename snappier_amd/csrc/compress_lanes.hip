@@ -116,26 +116,29 @@ __device__ __forceinline__ u32 lane_emit_literal16(const LaneCtx& c, u32 op, u32
 }
 
 // EmitCopyAtMost64*  SnappyCompressor.cs:467-505
-__device__ __forceinline__ u32 lane_emit_copy64(u8* dst, u32 op, u32 off, u32 len)
+// `cap` > 0: the tag is written as ONE 4-byte store (the reference does the same, :467-505 "writes 4 B blind"); the byte
+// or two beyond the tag are overwritten by whatever is emitted next and still lie inside MaxCompressedLength.
+__device__ __forceinline__ u32 lane_emit_copy64(u8* dst, u32 op, u32 off, u32 len, u32 cap)
 {
     u8* o = dst + op;
-    if (len < 12 && off < 2048) {
-        o[0] = static_cast<u8>(1u | ((len - 4) << 2) | ((off >> 8) << 5));
-        o[1] = static_cast<u8>(off);
-        return op + 2;
+    const bool one = len < 12 && off < 2048;
+    const u32 w = one ? (1u | ((len - 4) << 2) | ((off >> 8) << 5) | ((off & 0xffu) << 8)) : (2u | ((len - 1) << 2) | (off << 8));
+    if (op + 4 <= cap) {
+        st32u(o, w);
+    } else {
+        o[0] = static_cast<u8>(w);
+        o[1] = static_cast<u8>(w >> 8);
+        if (!one) o[2] = static_cast<u8>(w >> 16);
     }
-    o[0] = static_cast<u8>(2u | ((len - 1) << 2));
-    o[1] = static_cast<u8>(off);
-    o[2] = static_cast<u8>(off >> 8);
-    return op + 3;
+    return op + (one ? 2u : 3u);
 }
 
 // EmitCopyLenLessThan12 / EmitCopyLenGreaterThanOrEqualTo12  SnappyCompressor.cs:507-543
-__device__ __forceinline__ u32 lane_emit_copy(u8* dst, u32 op, u32 off, u32 len)
+__device__ __forceinline__ u32 lane_emit_copy(u8* dst, u32 op, u32 off, u32 len, u32 cap = 0)
 {
-    while (len >= 68) { op = lane_emit_copy64(dst, op, off, 64); len -= 64; }
-    if (len > 64) { op = lane_emit_copy64(dst, op, off, 60); len -= 60; }
-    return lane_emit_copy64(dst, op, off, len);
+    while (len >= 68) { op = lane_emit_copy64(dst, op, off, 64, cap); len -= 64; }
+    if (len > 64) { op = lane_emit_copy64(dst, op, off, 60, cap); len -= 60; }
+    return lane_emit_copy64(dst, op, off, len, cap);
 }
 
 // FindMatchLength  SnappyCompressor.cs:562-688: bytes s1[k] == s2[k] for k < result, s2 + result <= n
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     // ~10 trips per loop trip, and the loop trip is what 64 lanes pay together.)
     const u32 lit_cap = lit_blind ? 32u + n + n / 6u : 0u;            // blind 16-byte literal stores stay inside MaxCompressedLength
     while (__any(mode != kDone)) {
+        u32 cp_len = 0, cp_off = 0;                                     // the copy this trip ends with, emitted once below
         const bool post = mode == kPost;
         const bool scanning = mode == kScan || post;
         u32 p[kSlots], nx[kSlots], sk[kSlots], d[kSlots], h[kSlots], cv[kSlots];
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
             }
             if (finished) {
                 ip = base + mlen;
-                op = lane_emit_copy(c.dst, op, base - cand, mlen);     // :371-379
+                cp_len = mlen;                                         // :371-379
+                cp_off = base - cand;
                 mode = ip >= limit ? kDone : kPost;                    // :381-384
             }
         }
@@ -353,8 +358,9 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                         else mlen = 16;
                         if (mlen < 16) {
                             ip = base + mlen;
-                            op = lane_emit_copy(c.dst, op, base - cand, mlen);     // :371-379
-                            mode = ip >= limit ? kDone : kPost;                    // :381-384
+                            cp_len = mlen;                              // :371-379
+                            cp_off = base - cand;
+                            mode = ip >= limit ? kDone : kPost;        // :381-384
                         } else {
                             mode = kExtend;
                         }
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 }
             }
         }
+        if (cp_len) op = lane_emit_copy(c.dst, op, cp_off, cp_len, lit_cap);   // after this trip's literal, if any
     }
 #else
     if (n >= 15) {                                                     // :190
