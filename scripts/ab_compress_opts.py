@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Same-process A/B of the lane compressor's runtime options (SNAPPIER_HIP_CL_OPTS is read per launch): identical
+workspace placement, launches interleaved.  Usage: ab_compress_opts.py 7 5 3 1  -> mean ms per option mask."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import snappier_amd as S
+from snappier_amd import batch as SB, datagen as SD
+masks = sys.argv[1:] or ["7", "5", "3", "1"]
+nb = 163840
+html = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "testdata", "html"), "rb").read()
+cd = SB.BlockCodec(0, S.HASH_CRC32C)
+raw = SD.html_like_blocks(html, 0, nb, "cuda")
+in_off, in_len = cd.uniform_layout(nb)
+comp = torch.empty(nb * cd.comp_stride, dtype=torch.uint8, device="cuda")
+comp_off = torch.arange(nb, dtype=torch.int64, device="cuda") * cd.comp_stride
+def run():
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); r = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1), r
+run()
+res = {m: [] for m in masks}
+ref = None
+for rep in range(5):
+    for m in masks:
+        os.environ["SNAPPIER_HIP_CL_OPTS"] = m
+        ms, (_, _, out_len, st) = run()
+        res[m].append(round(ms, 2))
+        sig = int(out_len.to(torch.int64).sum().item())
+        ref = sig if ref is None else ref
+        assert sig == ref and int((st != 0).sum()) == 0
+print(json.dumps({m: {"ms": v, "mean": round(sum(v) / len(v), 2)} for m, v in res.items()}))

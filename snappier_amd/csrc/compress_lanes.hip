@@ -84,10 +84,19 @@ __device__ __forceinline__ u32 lane_emit_literal(const LaneCtx& c, u32 op, u32 s
 // EmitLiteral (:418-464) with the first 16 bytes of the literal already in registers (`first`): a literal of <= 16 bytes
 // costs no load at all.  `cap` > 0: the lane's output area holds MaxCompressedLength bytes, so a 16-byte store that
 // overshoots the literal is harmless (the next tag overwrites the excess) whenever it still ends inside the area.
-__device__ __forceinline__ u32 lane_emit_literal16(const LaneCtx& c, u32 op, u32 s, u32 len, const snp_u128_unaligned& first, u32 cap)
+__device__ __forceinline__ u32 lane_emit_literal16(const LaneCtx& c, u32 op, u32 s, u32 len, const snp_u128_unaligned& first, u32 cap, bool merge)
 {
     u8* o = c.dst + op;
     const u32 k = len - 1;
+    if (merge && len <= 15 && op + 16 <= cap) {                        // tag + body in ONE 16-byte store (the common case)
+        snp_u128_unaligned w;
+        w.v[0] = (first.v[0] << 8) | (k << 2);
+        w.v[1] = __builtin_amdgcn_alignbit(first.v[1], first.v[0], 24);
+        w.v[2] = __builtin_amdgcn_alignbit(first.v[2], first.v[1], 24);
+        w.v[3] = __builtin_amdgcn_alignbit(first.v[3], first.v[2], 24);
+        *reinterpret_cast<snp_u128_unaligned*>(o) = w;
+        return op + 1 + len;
+    }
     u32 hdr;
     if (k < 60) { o[0] = static_cast<u8>(k << 2); hdr = 1; }
     else if (k < 256) { o[0] = static_cast<u8>(60u << 2); o[1] = static_cast<u8>(k); hdr = 2; }
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     //           from registers and a match shorter than 16 finished without another trip.
     // (The first version waited for each of these in turn plus a load per literal piece and four extension steps:
     // ~10 trips per loop trip, and the loop trip is what 64 lanes pay together.)
-    const u32 lit_cap = lit_blind ? 32u + n + n / 6u : 0u;            // blind 16-byte literal stores stay inside MaxCompressedLength
+    const u32 lit_cap = (lit_blind & 1) ? 32u + n + n / 6u : 0u;            // blind 16-byte literal stores stay inside MaxCompressedLength
     while (__any(mode != kDone)) {
         u32 cp_len = 0, cp_off = 0;                                     // the copy this trip ends with, emitted once below
         const bool post = mode == kPost;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                     const u64 x1 = (static_cast<u64>(cb.v[2] ^ pb.v[2])) | (static_cast<u64>(cb.v[3] ^ pb.v[3]) << 32);
                     hit = static_cast<u32>(x0) == 0;                    // :334 / :398
                     if (hit) {
-                        if (!post) op = lane_emit_literal16(c, op, next_emit, wp - next_emit, lb, lit_cap);   // :347
+                        if (!post) op = lane_emit_literal16(c, op, next_emit, wp - next_emit, lb, lit_cap, (lit_blind & 2) != 0);   // :347
                         base = wp;
                         cand = wpos;
                         if (x0) mlen = static_cast<u32>(__builtin_ctzll(x0)) >> 3;
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 }
             }
         }
-        if (cp_len) op = lane_emit_copy(c.dst, op, cp_off, cp_len, lit_cap);   // after this trip's literal, if any
+        if (cp_len) op = lane_emit_copy(c.dst, op, cp_off, cp_len, (lit_blind & 4) ? lit_cap : 0u);   // after this trip's literal, if any
     }
 #else
     if (n >= 15) {                                                     // :190
@@ -490,8 +499,12 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     u32 per = env ? static_cast<u32>(atoi(env)) : (nblocks >= 16384 ? 64u : 16u);   // measured: scripts/sweep_layouts.py
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
     const u32 grid = (nblocks + per - 1) / per;
-    const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");           // test knob: never overshoot a short literal
-    const int lit_blind = !(ex && ex[0] == '1');
+    // Output-store options (bit 0: a short literal may overshoot with one 16-byte store, bit 1: tag + body of a literal in
+    // one store, bit 2: a copy tag as one 4-byte store).  SNAPPIER_HIP_EXACT_LITERALS=1 = none (exact-length stores only);
+    // SNAPPIER_HIP_CL_OPTS=<mask> picks a subset -- read per launch, so one process can A/B on the same workspace.
+    const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");
+    const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
+    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 7) : 7;
     if (variant == SNP_HASH_CRC32C)
         hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_CRC32C>, dim3(grid), dim3(per), 0, stream, in, in_off, in_len,
                            nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind);
