@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import snappier_amd as S
 from snappier_amd import batch as SB, datagen as SD
+# arguments: option masks, or NAME=VALUE pairs of any per-launch environment knob (e.g. SNAPPIER_HIP_LANES_PER_WAVE=32)
 masks = sys.argv[1:] or ["7", "5", "3", "1"]
 nb = 163840
 html = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "testdata", "html"), "rb").read()
@@ -23,7 +24,11 @@ res = {m: [] for m in masks}
 ref = None
 for rep in range(5):
     for m in masks:
-        os.environ["SNAPPIER_HIP_CL_OPTS"] = m
+        if "=" in m:
+            k, v = m.split("=", 1)
+            os.environ[k] = v
+        else:
+            os.environ["SNAPPIER_HIP_CL_OPTS"] = m
         ms, (_, _, out_len, st) = run()
         res[m].append(round(ms, 2))
         sig = int(out_len.to(torch.int64).sum().item())

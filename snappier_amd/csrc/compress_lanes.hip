@@ -20,12 +20,12 @@
 #define SNP_CL_FLAT 1     // 1: flat per-lane state machine (default); 0: the reference's nested loops, verbatim
 #endif
 #ifndef SNP_CL_SLOTS
-#define SNP_CL_SLOTS 2    // probes of one lane's scan issued together (flat layout only; measured: 2 best, >= 4 costs bandwidth)
+#define SNP_CL_SLOTS 1    // probes of one lane's scan issued together (same-process A/B, scripts/ab_compress_opts.py: 1 is 1.5 % faster than 2; 3 and 4 cost bandwidth)
 #endif
 
 namespace {
 
-constexpr u32 kSlots = SNP_CL_SLOTS;
+constexpr u32 kDefaultSlots = SNP_CL_SLOTS;
 
 constexpr u32 crc_step32(u32 x)
 {
@@ -163,7 +163,7 @@ __device__ __forceinline__ u32 lane_find_match_length(const u8* src, u32 s1, u32
     return matched;
 }
 
-template <int VARIANT>
+template <int VARIANT, u32 kSlots>
 __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                             const u32* __restrict__ in_len, u32 nblocks,
                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
@@ -256,9 +256,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
             const u8* a = c.src + cand + mlen;
             const u8* bq = c.src + base + mlen;
             xa0 = *reinterpret_cast<const snp_u128_unaligned*>(a);
-            xa1 = *reinterpret_cast<const snp_u128_unaligned*>(a + 16);
             xb0 = *reinterpret_cast<const snp_u128_unaligned*>(bq);
-            xb1 = *reinterpret_cast<const snp_u128_unaligned*>(bq + 16);
+            if (!(lit_blind & 8)) {                                     // option bit 3: only 16 + 16 bytes per trip
+                xa1 = *reinterpret_cast<const snp_u128_unaligned*>(a + 16);
+                xb1 = *reinterpret_cast<const snp_u128_unaligned*>(bq + 16);
+            }
         }
         // ---- trip 2: hashes and table entries ----------------------------------------------------------------------
         if (scanning) {
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 finished = true;
                 if (x0) mlen += static_cast<u32>(__builtin_ctzll(x0)) >> 3;
                 else if (x1) mlen += 8 + (static_cast<u32>(__builtin_ctzll(x1)) >> 3);
+                else if (lit_blind & 8) { mlen += 16; finished = false; }
                 else if (x2) mlen += 16 + (static_cast<u32>(__builtin_ctzll(x2)) >> 3);
                 else if (x3) mlen += 24 + (static_cast<u32>(__builtin_ctzll(x3)) >> 3);
                 else { mlen += 32; finished = false; }
@@ -504,12 +507,15 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // SNAPPIER_HIP_CL_OPTS=<mask> picks a subset -- read per launch, so one process can A/B on the same workspace.
     const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");
     const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
-    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 7) : 7;
-    if (variant == SNP_HASH_CRC32C)
-        hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_CRC32C>, dim3(grid), dim3(per), 0, stream, in, in_off, in_len,
-                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind);
-    else
-        hipLaunchKernelGGL(k_compress_lanes<SNP_HASH_MUL>, dim3(grid), dim3(per), 0, stream, in, in_off, in_len,
-                           nblocks, out, out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind);
+    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 15) : 7;
+    // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
+    const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
+    const u32 slots = se ? static_cast<u32>(atoi(se)) : kDefaultSlots;
+#define SNP_LAUNCH_CL(V, S)                                                                                          \
+    hipLaunchKernelGGL((k_compress_lanes<V, S>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
+                       out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind)
+    if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 1); else SNP_LAUNCH_CL(SNP_HASH_CRC32C, 2); }
+    else { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_MUL, 1); else SNP_LAUNCH_CL(SNP_HASH_MUL, 2); }
+#undef SNP_LAUNCH_CL
     return hipGetLastError();
 }
