@@ -163,6 +163,43 @@ __device__ __forceinline__ u32 lane_find_match_length(const u8* src, u32 s1, u32
     return matched;
 }
 
+// ---- output staging (option bit 4) -------------------------------------------------------------------------------
+// A lane emits its compressed stream in pieces of 2..17 bytes (a copy tag, a short literal): thousands of partial-sector
+// stores per fragment, each one a write request to L2.  Staged, the pieces go into a per-lane LDS buffer (unaligned LDS
+// stores) and leave as whole 64-byte runs: four 16-byte global stores per 64 bytes of output.  The buffer holds the
+// bytes [flushed, op) of the lane's output at offset 0.. ; it is drained before anything is written around it.
+constexpr u32 kStageStride = 100;      // bytes of LDS per lane: 96 usable (63 pending + 16 + 4 blind), odd dword stride
+
+struct OutStage {
+    u8* lds;        // this lane's buffer
+    u32 flushed;    // output bytes [0, flushed) are in global memory
+};
+
+__device__ __forceinline__ void stage_flush64(const LaneCtx& c, OutStage& st)
+{
+    u8* g = c.dst + st.flushed;
+#pragma unroll
+    for (u32 i = 0; i < 64; i += 16)
+        *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + i);
+    const snp_u128_unaligned t0 = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + 64);
+    const snp_u128_unaligned t1 = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + 80);
+    *reinterpret_cast<snp_u128_unaligned*>(st.lds) = t0;
+    *reinterpret_cast<snp_u128_unaligned*>(st.lds + 16) = t1;
+    st.flushed += 64;
+}
+
+// Write out whatever is staged (exact bytes), e.g. before a long literal is copied directly.
+__device__ __forceinline__ void stage_drain(const LaneCtx& c, OutStage& st, u32 op)
+{
+    const u32 fill = op - st.flushed;
+    u8* g = c.dst + st.flushed;
+    u32 i = 0;
+    for (; i + 16 <= fill; i += 16)
+        *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + i);
+    for (; i < fill; ++i) g[i] = st.lds[i];
+    st.flushed = op;
+}
+
 template <int VARIANT, u32 kSlots>
 __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                             const u32* __restrict__ in_len, u32 nblocks,
@@ -176,8 +213,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
             lut[e >> 8][e & 255u] = static_cast<u16>(crc_step32((e & 255u) << (8 * (e >> 8))) & 0x7ffeu);
         __syncthreads();
     }
+    __shared__ u8 s_out[SNP_WAVE * kStageStride];
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
+    const bool staged = (lit_blind & 16) != 0;
+    OutStage stg{s_out + threadIdx.x * kStageStride, 0};
 
     LaneCtx c;
     c.src = in + in_off[b];
@@ -194,6 +234,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
         while (v >= 128) { c.dst[op++] = static_cast<u8>(v | 0x80u); v >>= 7; }
         c.dst[op++] = static_cast<u8>(v);
     }
+    stg.flushed = op;                                                   // the preamble went straight to global memory
 
     u32 ip = 0;
 #if SNP_CL_FLAT
@@ -224,6 +265,8 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     const u32 lit_cap = (lit_blind & 1) ? 32u + n + n / 6u : 0u;            // blind 16-byte literal stores stay inside MaxCompressedLength
     while (__any(mode != kDone)) {
         u32 cp_len = 0, cp_off = 0;                                     // the copy this trip ends with, emitted once below
+        u32 lit_len = 0;                                                // the literal this trip ends with (staged mode: emitted below)
+        snp_u128_unaligned lit16 = {};
         const bool post = mode == kPost;
         const bool scanning = mode == kScan || post;
         u32 p[kSlots], nx[kSlots], sk[kSlots], d[kSlots], h[kSlots], cv[kSlots];
@@ -362,7 +405,10 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                     const u64 x1 = (static_cast<u64>(cb.v[2] ^ pb.v[2])) | (static_cast<u64>(cb.v[3] ^ pb.v[3]) << 32);
                     hit = static_cast<u32>(x0) == 0;                    // :334 / :398
                     if (hit) {
-                        if (!post) op = lane_emit_literal16(c, op, next_emit, wp - next_emit, lb, lit_cap, (lit_blind & 2) != 0);   // :347
+                        if (!post) {                                    // :347
+                            if (staged) { lit_len = wp - next_emit; lit16 = lb; }
+                            else op = lane_emit_literal16(c, op, next_emit, wp - next_emit, lb, lit_cap, (lit_blind & 2) != 0);
+                        }
                         base = wp;
                         cand = wpos;
                         if (x0) mlen = static_cast<u32>(__builtin_ctzll(x0)) >> 3;
@@ -393,8 +439,40 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 }
             }
         }
-        if (cp_len) op = lane_emit_copy(c.dst, op, cp_off, cp_len, (lit_blind & 4) ? lit_cap : 0u);   // after this trip's literal, if any
+        if (!staged) {
+            if (cp_len) op = lane_emit_copy(c.dst, op, cp_off, cp_len, (lit_blind & 4) ? lit_cap : 0u);   // after this trip's literal, if any
+        } else {
+            // literal (next_emit is still the literal's start: it only changes when a scan begins), then the copy
+            if (lit_len) {
+                if (lit_len <= 15) {                                    // tag + body: one 16-byte LDS store
+                    snp_u128_unaligned w;
+                    w.v[0] = (lit16.v[0] << 8) | ((lit_len - 1) << 2);
+                    w.v[1] = __builtin_amdgcn_alignbit(lit16.v[1], lit16.v[0], 24);
+                    w.v[2] = __builtin_amdgcn_alignbit(lit16.v[2], lit16.v[1], 24);
+                    w.v[3] = __builtin_amdgcn_alignbit(lit16.v[3], lit16.v[2], 24);
+                    *reinterpret_cast<snp_u128_unaligned*>(stg.lds + (op - stg.flushed)) = w;
+                    op += 1 + lit_len;
+                } else {                                                // long: straight to global memory, around the stage
+                    stage_drain(c, stg, op);
+                    op = lane_emit_literal16(c, op, next_emit, lit_len, lit16, 0u, false);
+                    stg.flushed = op;
+                }
+            }
+            u32 len = cp_len;
+            while (len) {                                               // EmitCopy  :507-543, one tag per turn
+                const u32 piece = len >= 68 ? 64u : len > 64 ? 60u : len;
+                const bool one = piece < 12 && cp_off < 2048;
+                const u32 w = one ? (1u | ((piece - 4) << 2) | ((cp_off >> 8) << 5) | ((cp_off & 0xffu) << 8))
+                                  : (2u | ((piece - 1) << 2) | (cp_off << 8));
+                st32u(stg.lds + (op - stg.flushed), w);
+                op += one ? 2u : 3u;
+                len -= piece;
+                if (op - stg.flushed >= 64) stage_flush64(c, stg);
+            }
+            if (op - stg.flushed >= 64) stage_flush64(c, stg);
+        }
     }
+    if (staged) stage_drain(c, stg, op);
 #else
     if (n >= 15) {                                                     // :190
         const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << (31u - __clz(n - 1)));   // HashTable.cs:57-71
@@ -503,11 +581,12 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
     const u32 grid = (nblocks + per - 1) / per;
     // Output-store options (bit 0: a short literal may overshoot with one 16-byte store, bit 1: tag + body of a literal in
-    // one store, bit 2: a copy tag as one 4-byte store).  SNAPPIER_HIP_EXACT_LITERALS=1 = none (exact-length stores only);
+    // one store, bit 2: a copy tag as one 4-byte store, bit 3: 16- instead of 32-byte extension trips, bit 4: output staged
+    // in LDS and written as whole 64-byte runs; default 1+2+4+16).  SNAPPIER_HIP_EXACT_LITERALS=1 = none (exact-length stores only);
     // SNAPPIER_HIP_CL_OPTS=<mask> picks a subset -- read per launch, so one process can A/B on the same workspace.
     const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");
     const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
-    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 15) : 7;
+    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 31) : 23;
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
     const u32 slots = se ? static_cast<u32>(atoi(se)) : kDefaultSlots;

@@ -327,13 +327,15 @@ def test_decompress_batch_per_block_status(codec):
     assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
 
 
-@pytest.mark.parametrize("layout", ["wave", "wave-staged", "wave-unstaged", "lanes", "lanes-exact"])
+@pytest.mark.parametrize("layout", ["wave", "wave-staged", "wave-unstaged", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31"])
 def test_compress_layouts_are_bit_identical(layout, monkeypatch):
     """Both compressor layouts (one fragment per wavefront with the table in LDS; one fragment per lane with the table
     in an HBM workspace) must give the oracle's bytes on every kind of input, ragged lengths included."""
     monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout.split("-")[0])
     if layout.endswith("-exact"):       # short literals stored with exact-length stores instead of one 16-byte store
         monkeypatch.setenv("SNAPPIER_HIP_EXACT_LITERALS", "1")
+    if "-opts" in layout:               # lane kernel with another set of output-store options (default 23; 7 = no LDS staging)
+        monkeypatch.setenv("SNAPPIER_HIP_CL_OPTS", layout.split("-opts")[1])
     if layout.endswith("staged"):       # wave kernel with / without the fragment staged in LDS (default: by batch size)
         monkeypatch.setenv("SNAPPIER_HIP_STAGED", "1" if layout == "wave-staged" else "0")
     html = read_testdata("html")
