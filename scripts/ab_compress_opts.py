@@ -11,7 +11,17 @@ masks = sys.argv[1:] or ["7", "5", "3", "1"]
 nb = 163840
 html = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "testdata", "html"), "rb").read()
 cd = SB.BlockCodec(0, S.HASH_CRC32C)
-raw = SD.html_like_blocks(html, 0, nb, "cuda")
+kind = os.environ.get("DATA", "html")
+if kind == "low_entropy":
+    raw = SD.low_entropy_blocks(0, nb, "cuda")
+elif kind == "mixed":
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from conftest import CORPUS
+    TD = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "testdata")
+    files = [open(os.path.join(TD, "html"), "rb").read() * 4 if n == "html_x_4" else open(os.path.join(TD, n), "rb").read() for n in CORPUS]
+    raw = SD.corpus_blocks(files, 0, nb, SD.MIXED_SEED, "cuda")
+else:
+    raw = SD.html_like_blocks(html, 0, nb, "cuda")
 in_off, in_len = cd.uniform_layout(nb)
 comp = torch.empty(nb * cd.comp_stride, dtype=torch.uint8, device="cuda")
 comp_off = torch.arange(nb, dtype=torch.int64, device="cuda") * cd.comp_stride
