@@ -126,6 +126,9 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
     }
 }
 
+#ifndef SNP_D_STAGE
+#define SNP_D_STAGE 2048    // queued mode: a batch whose output is contiguous and at most this long is assembled in LDS (0 = off)
+#endif
 #ifndef SNP_D_WALK
 #define SNP_D_WALK 1        // queued mode, finding the tag starts of a window: 0 scalar walk (4 tags per step), 1 pointer doubling through LDS
 #endif
@@ -376,6 +379,9 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
     if (FRONT == 2) {
         __shared__ u32 q_ostart[128], q_arg[128], q_meta[128];          // ring: output offset | copy offset or literal
         __shared__ u8 s_reach[64];                                      // tag-start flags of the window being parsed
+#if SNP_D_STAGE
+        __shared__ u8 s_stage[SNP_D_STAGE + 64];                        // the current batch's output bytes (staged batches)
+#endif
         __shared__ u64 s_busy[65];                                      // one bit per output byte of the batch that a pending tag still has to write
         u32 head = 0, count = 0;                                        // input position | length + literal flag
         bool parsing = st == SNP_OK;
@@ -493,6 +499,95 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
             const u32 mark = read_lane(e_ostart, 0);                    // everything before the first queued tag is complete
             const bool ready = act && (e_lit || (e_off >= e_len && e_ostart - e_off + e_len <= mark));
             if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if SNP_D_STAGE
+            // Staged batch.  When the batch's output is one contiguous run of at most SNP_D_STAGE bytes it is assembled
+            // in LDS and leaves as one coalesced copy: tags write their 1..64 bytes into the stage (LDS stores instead of
+            // ~8 partial-sector global store instructions per pass), tags that depend on this batch's own output read it
+            // from the stage at LDS latency, and the wave then writes the whole run, 16 bytes per lane per instruction.
+            {
+                const u32 my_end = e_ostart + e_len;
+                const u32 prev_end = static_cast<u32>(__shfl_up(static_cast<int>(my_end), 1, 64));
+                const bool gap = act && lane > 0 && e_ostart != prev_end;      // a > 64-byte literal was copied at parse time
+                const u32 span = read_lane(my_end, ne - 1) - mark;
+                if (ballot64(gap) == 0ull && span <= SNP_D_STAGE) {
+                    u8* const my = s_stage + (e_ostart - mark);
+                    const u32 s_lo = e_ostart - e_off;
+                    if (ready) lane_copy(my, e_lit ? src + e_arg : dst + s_lo, e_len);
+                    u64 pend = ballot64(act && !ready);
+                    DPROF_ADD(0, 1);
+                    DPROF_ADD(1, ne);
+                    DPROF_ADD(5, __builtin_popcountll(pend));
+                    DPROF_ADD(6, 1);                                    // staged batches
+                    DPROF_TIME(12);
+                    if (pend) {
+                        // second lane-parallel pass: sources that lie entirely inside the batch and do not touch the
+                        // output of a tag that is still pending (bitmap of pending output bytes, as below)
+                        bool blocked = e_off < e_len || s_lo < mark;    // pattern copies and sources straddling `mark`: serial finish
+                        const bool mine = (pend >> lane) & 1ull;
+                        if (pend & (pend - 1)) {
+                            s_busy[lane] = 0ull;
+                            lanes_sync_lds();
+                            if (mine) {
+                                const u32 r = e_ostart - mark, b0 = r & 63u;
+                                const u64 m = e_len >= 64 ? ~0ull : ((1ull << e_len) - 1ull);
+                                atomicOr(reinterpret_cast<unsigned long long*>(&s_busy[r >> 6]), static_cast<unsigned long long>(m << b0));
+                                if (b0 && (m >> (64u - b0)))
+                                    atomicOr(reinterpret_cast<unsigned long long*>(&s_busy[(r >> 6) + 1]), static_cast<unsigned long long>(m >> (64u - b0)));
+                            }
+                            lanes_sync_lds();
+                            if (mine && !blocked) {
+                                const u32 lo = s_lo - mark, b0 = lo & 63u;
+                                const u64 m = e_len >= 64 ? ~0ull : ((1ull << e_len) - 1ull);
+                                const u64 w0 = s_busy[lo >> 6], w1 = s_busy[(lo >> 6) + 1];
+                                blocked = ((w0 & (m << b0)) | (b0 ? (w1 & (m >> (64u - b0))) : 0ull)) != 0ull;
+                            }
+                        }
+                        const bool ready2 = mine && !blocked;
+                        lanes_sync_lds();
+                        if (ready2) lane_copy(my, s_stage + (s_lo - mark), e_len);
+                        pend &= ~ballot64(ready2);
+                        DPROF_ADD(4, __builtin_popcountll(pend));
+                        DPROF_TIME(13);
+                        while (pend) {                                  // the rest in order, whole wave per tag, a byte per lane
+                            const u32 f = static_cast<u32>(__builtin_ctzll(pend));
+                            pend &= pend - 1;
+                            const u32 f_o = read_lane(e_ostart, f), f_off = read_lane(e_off, f), f_len = read_lane(e_len, f);
+                            u32 sidx = lane;
+                            if (f_off < f_len) {
+#pragma unroll
+                                for (int sh = 5; sh >= 0; --sh) {
+                                    const u32 t = f_off << sh;
+                                    sidx = min(sidx, sidx - t);
+                                }
+                            }
+                            const u32 spos = f_o - f_off + sidx;        // output position this lane's byte comes from
+                            lanes_sync_lds();
+                            u32 byte = 0;
+                            if (f_o - f_off >= mark) {                  // the whole source lies in this batch
+                                if (lane < f_len) byte = s_stage[spos - mark];
+                            } else if (lane < f_len) {                  // it starts before the batch: those bytes are in global memory
+                                if (spos < mark) byte = dst[spos];
+                                else byte = s_stage[spos - mark];       // (two branches: one select would make this a flat load)
+                            }
+                            lanes_sync_lds();
+                            if (lane < f_len) s_stage[f_o - mark + lane] = static_cast<u8>(byte);
+                        }
+                    }
+                    // the whole run, coalesced
+                    lanes_sync_lds();
+                    u8* const g = dst + mark;
+                    for (u32 i = lane * 16; i + 16 <= span; i += SNP_WAVE * 16)
+                        *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(s_stage + i);
+                    const u32 tail = span & ~15u;
+                    if (tail + lane < span) g[tail + lane] = s_stage[tail + lane];
+                    lanes_sync_lds();
+                    head = (head + ne) & 127u;
+                    count -= ne;
+                    DPROF_TIME(14);
+                    continue;
+                }
+            }
+#endif
             if (ready) lane_copy(dst + e_ostart, e_lit ? src + e_arg : dst + (e_ostart - e_off), e_len);
             u64 pend = ballot64(act && !ready);
             DPROF_ADD(0, 1);                                            // execution batches
