@@ -508,8 +508,15 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 const u32 my_end = e_ostart + e_len;
                 const u32 prev_end = static_cast<u32>(__shfl_up(static_cast<int>(my_end), 1, 64));
                 const bool gap = act && lane > 0 && e_ostart != prev_end;      // a > 64-byte literal was copied at parse time
-                const u32 span = read_lane(my_end, ne - 1) - mark;
-                if (ballot64(gap) == 0ull && span <= SNP_D_STAGE) {
+                // the longest prefix of the batch that is contiguous and fits the stage (all of it, normally)
+                const u64 gapm = ballot64(gap);
+                u32 nst = static_cast<u32>(__builtin_popcountll(ballot64(act && my_end - mark <= SNP_D_STAGE)));
+                if (gapm) nst = min(nst, static_cast<u32>(__builtin_ctzll(gapm)));
+                if (nst >= 8) {
+                    const u32 ne = nst;                                 // (shadows: this batch is the prefix)
+                    const bool act = lane < ne;
+                    const bool ready = act && (e_lit || (e_off >= e_len && e_ostart - e_off + e_len <= mark));
+                    const u32 span = read_lane(my_end, ne - 1) - mark;
                     u8* const my = s_stage + (e_ostart - mark);
                     const u32 s_lo = e_ostart - e_off;
                     if (ready) lane_copy(my, e_lit ? src + e_arg : dst + s_lo, e_len);
