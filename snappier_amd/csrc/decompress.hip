@@ -129,6 +129,9 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
 #ifndef SNP_D_STAGE
 #define SNP_D_STAGE 2048    // queued mode: a batch whose output is contiguous and at most this long is assembled in LDS (0 = off)
 #endif
+#ifndef SNP_D_STAGE_MIN
+#define SNP_D_STAGE_MIN 2   // staged batches: shortest prefix worth staging (a lone tag before a > 64-byte literal takes the unstaged path)
+#endif
 #ifndef SNP_D_WALK
 #define SNP_D_WALK 1        // queued mode, finding the tag starts of a window: 0 scalar walk (4 tags per step), 1 pointer doubling through LDS
 #endif
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                 const u64 gapm = ballot64(gap);
                 u32 nst = static_cast<u32>(__builtin_popcountll(ballot64(act && my_end - mark <= SNP_D_STAGE)));
                 if (gapm) nst = min(nst, static_cast<u32>(__builtin_ctzll(gapm)));
-                if (nst >= 8) {
+                if (nst >= SNP_D_STAGE_MIN) {
                     const u32 ne = nst;                                 // (shadows: this batch is the prefix)
                     const bool act = lane < ne;
                     const bool ready = act && (e_lit || (e_off >= e_len && e_ostart - e_off + e_len <= mark));
