@@ -8,7 +8,7 @@ import snappier_amd as S
 from snappier_amd import batch as SB, datagen as SD
 # arguments: option masks, or NAME=VALUE pairs of any per-launch environment knob (e.g. SNAPPIER_HIP_LANES_PER_WAVE=32)
 masks = sys.argv[1:] or ["7", "5", "3", "1"]
-nb = 163840
+nb = int(os.environ.get("NB", "163840"))
 html = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "testdata", "html"), "rb").read()
 cd = SB.BlockCodec(0, S.HASH_CRC32C)
 kind = os.environ.get("DATA", "html")

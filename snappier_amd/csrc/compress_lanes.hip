@@ -577,7 +577,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // Fragments per wavefront: 64 when there are enough fragments to fill the chip that way; fewer (partially filled
     // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
     const char* env = getenv("SNAPPIER_HIP_LANES_PER_WAVE");
-    u32 per = env ? static_cast<u32>(atoi(env)) : (nblocks >= 16384 ? 64u : 16u);   // measured: scripts/sweep_layouts.py
+    u32 per = env ? static_cast<u32>(atoi(env)) : (nblocks >= 131072 ? 64u : nblocks >= 8192 ? 32u : 16u);   // measured: scripts/sweep_layouts.py
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
     const u32 grid = (nblocks + per - 1) / per;
     // Output-store options (bit 0: a short literal may overshoot with one 16-byte store, bit 1: tag + body of a literal in
@@ -586,10 +586,13 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // SNAPPIER_HIP_CL_OPTS=<mask> picks a subset -- read per launch, so one process can A/B on the same workspace.
     const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");
     const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
-    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 31) : 23;
+    // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
+    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 31) : (nblocks >= 32768 ? 23 : 7);
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
-    const u32 slots = se ? static_cast<u32>(atoi(se)) : kDefaultSlots;
+    // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
+    // one probe is 1.5 % faster at 163 840)
+    const u32 slots = se ? static_cast<u32>(atoi(se)) : (nblocks >= 131072 ? kDefaultSlots : 2u);
 #define SNP_LAUNCH_CL(V, S)                                                                                          \
     hipLaunchKernelGGL((k_compress_lanes<V, S>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
                        out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind)
