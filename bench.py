@@ -169,10 +169,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         alg = u_bytes + c_bytes                                     # U + C for compress, C + U for decompress
         # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per
-        # pass, same workload): per-block figures x blocks of this run.  See profiles/r01j_hbm_traffic.json for the caveat
+        # pass, same workload): per-block figures x blocks of this run.  See profiles/r01k_hbm_traffic.json for the caveat
         # on the gfx950 FETCH_SIZE calibration.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01j_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01k_hbm_traffic.json")) as f:
                 pmc = json.load(f)["kernels"]
         except OSError:
             pmc = {}
