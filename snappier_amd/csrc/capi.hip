@@ -58,7 +58,7 @@ struct snp_ctx {
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
     int dec_lds = 0;         // dynamic LDS bytes per decode wavefront (occupancy throttle)
     int decode_layout = 0;   // 0/1 wave-per-block (default), 2 block-per-lane (SNAPPIER_HIP_DECODE=lanes)
-    int table_tries = 4;     // candidates tried when a >= 1 GiB hash-table workspace is allocated (SNAPPIER_HIP_TABLE_TRIES)
+    int table_tries = 6;     // candidates tried when a >= 1 GiB hash-table workspace is allocated (SNAPPIER_HIP_TABLE_TRIES)
     u32 par_min = 4 * SNP_BLOCK_SIZE;   // single blocks at least this long are decoded one wavefront per 64 KiB fragment (0 = never)
     int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= 8192 fragments), 1 wave-per-fragment, 2 fragment-per-lane
     DevBuf in, out, meta, work, tables;
