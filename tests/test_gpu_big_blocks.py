@@ -56,12 +56,11 @@ def low_entropy_bytes(n: int) -> bytes:
 @pytest.fixture(params=["default", "min1", "off"])
 def ctx(request, monkeypatch):
     """default: parallel path from 256 KiB; min1: every block takes the parallel path; off: never."""
-    if request.param == "min1":
-        monkeypatch.setenv("SNAPPIER_HIP_PARALLEL_MIN", "1")
-    elif request.param == "off":
-        monkeypatch.setenv("SNAPPIER_HIP_PARALLEL_MIN", "0")
+    par_min = {"default": 262144, "min1": 1, "off": 0}[request.param]
+    monkeypatch.setenv("SNAPPIER_HIP_PARALLEL_MIN", str(par_min))       # explicit, whatever the caller's environment says
     c = S.Context(0, O.HASH_CRC32C)
-    c.par_min = {"default": 262144, "min1": 1, "off": 0}[request.param]
+    # the block-per-lane decoder (SNAPPIER_HIP_DECODE=lanes) never takes the fragment path
+    c.par_min = 0 if __import__("os").environ.get("SNAPPIER_HIP_DECODE") == "lanes" else par_min
     return c
 
 
