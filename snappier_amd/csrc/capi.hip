@@ -19,6 +19,8 @@ u32 snp_tag_index_entries(u32, u32);
 hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
 hipError_t snp_launch_compress(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int,
                                hipStream_t);
+hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
+                                   hipStream_t);
 hipError_t snp_launch_decompress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*,
                                        const u8*, hipStream_t);
 hipError_t snp_launch_compress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, void*,
@@ -60,7 +62,9 @@ struct snp_ctx {
     int decode_layout = 0;   // 0/1 wave-per-block (default), 2 block-per-lane (SNAPPIER_HIP_DECODE=lanes)
     int table_tries = 6;     // candidates tried when a >= 1 GiB hash-table workspace is allocated (SNAPPIER_HIP_TABLE_TRIES)
     u32 par_min = 4 * SNP_BLOCK_SIZE;   // single blocks at least this long are decoded one wavefront per 64 KiB fragment (0 = never)
-    int compress_mode = 0;   // 0 auto (fragment-per-lane kernel for batches >= 8192 fragments), 1 wave-per-fragment, 2 fragment-per-lane
+    int compress_mode = 0;   // 0 auto, 1 wave-per-fragment single-token rounds (compress.hip), 2 fragment-per-lane with HBM tables
+                             // (compress_lanes.hip), 3 wave-per-fragment multi-token windows (compress_win.hip)
+    int win_np = 2;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2)
     DevBuf in, out, meta, work, tables;
     uint64_t counters[2] = {0, 0};   // snp_ctx_counter
     std::string err;
@@ -81,7 +85,10 @@ struct snp_ctx {
     bool launch_compress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
                          u32* out_len, i32* status, int emit_varint)
     {
-        const bool lanes = compress_mode == 2 || (compress_mode == 0 && nblocks >= 8192);   // measured crossover (scripts/sweep_layouts.py)
+        if (compress_mode == 3 || compress_mode == 0)
+            return check(snp_launch_compress_win(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
+                                                 emit_varint, win_np, stream), "compress (windows) launch");
+        const bool lanes = compress_mode == 2;
         if (!lanes)
             return check(snp_launch_compress(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
                                              emit_varint, stream), "compress launch");
@@ -184,7 +191,9 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->dec_lds = dl ? (atoi(dl) / 256) * 256 : kDefaultDecLds;
     // SNAPPIER_HIP_COMPRESS=wave|lanes pins the compressor layout (default: by batch size)
     const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
-    c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : 0;
+    c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : (cm && strncmp(cm, "win", 3) == 0) ? 3 : 0;
+    const char* wn = getenv("SNAPPIER_HIP_WIN_NP");
+    if (wn) c->win_np = atoi(wn) == 1 ? 1 : 2;
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
     // fragments decoded in parallel (tag_index.hip); 0 = always one wavefront per block
     const char* tt = getenv("SNAPPIER_HIP_TABLE_TRIES");

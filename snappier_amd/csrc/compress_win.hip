@@ -1,0 +1,665 @@
+// compress_win.hip -- Snappy fragment compression, one <= 64 KiB fragment per wavefront, u16 hash table in LDS,
+// MULTI-TOKEN speculative rounds (gfx950).  Bit-exact with SnappyCompressor.CompressFragment
+// (Snappier/Internal/SnappyCompressor.cs:174-415) for both TableEntry hashes (HashTable.cs:91-126).
+// tests/window_model.c is the executable CPU model of exactly this algorithm (checked against the oracle).
+//
+// The reference parse is a serial chain of probe EVENTS in position order.  Its state is
+//     (S, pos, pend):  S = start of the current scan (the OUTER iteration's ip+1, :198-199), pos = next position to
+//                      probe, pos == S-1 = the probe that follows a copy (:395-398), pend = "insert pos-1 first" (:393-394)
+//     probe p legal iff p == S-1 or p + bb <= limit, bb = (32 + p - S) >> 5     (skip = 32 + distance, :227,319-323;
+//                      the unrolled 16-probe section :230-313 obeys the same rule)
+//     miss: pos = p + bb (S after the post-copy probe)      hit: literal, copy of len m, ip = p + m;
+//                      ip >= limit -> remainder (:381-384), else S = ip+1, pos = ip, pend
+// DENSE round (scans in their stride-1 zone, i.e. html/text-like data): all W = 64*NP consecutive positions from pos
+// are speculated against the table as it stood BEFORE the round: 16 input bytes per position in registers, hash,
+// candidate gather from LDS, 16 candidate bytes from the fragment, hit + match length (up to kCap bytes per lane,
+// longer matches are finished by the whole wave only if the parse really visits them).  A scalar walk over ballot
+// masks then follows the state machine through the window -- several tokens per round -- and yields the set of
+// positions the serial parse writes to the table (probes and ip-1 inserts).  The speculation was exact iff those
+// positions have pairwise distinct buckets: they publish to the table and read back; on a repeat the round is cut at
+// the first position whose bucket an earlier one of the round already used (min-position-wins publish makes every
+// later duplicate read a smaller position), the table is rolled back and the prefix re-walked.
+// SPARSE round (scan beyond its 33rd probe -- incompressible data -- and the fragment tail): lane j speculates probe
+// slot j of the current scan (offsets D[], the skip heuristic's sequence), at most one token per round.
+// Tokens (position, length, offset) queue in LDS and are turned into literal/copy tags 64 at a time, one per lane
+// (EmitLiteral :418-464, EmitCopy* :467-543), so the emission cost is paid per 64 tokens, not per round.
+// LDS per wavefront: 32 KiB table + 2 KiB CRC-step table + 1 KiB token ring  -> 4 fragments per CU.
+#include <cstdlib>
+
+#include "snp_device.h"
+
+#ifndef SNP_W_CAP
+#define SNP_W_CAP 48      // bytes of match length a hit position resolves by itself (multiple of 16)
+#endif
+#ifndef SNP_W_PROF
+#define SNP_W_PROF 0
+#endif
+
+namespace {
+
+constexpr u32 kCap = SNP_W_CAP;
+constexpr u32 kNone = 0xffffffffu;
+
+// ---- compile-time tables -----------------------------------------------------------------------------------
+struct ProbeTableW {
+    u16 d[704];
+    constexpr ProbeTableW() : d{}
+    {
+        u32 v = 0;
+        for (int i = 0; i < 704; ++i) {
+            d[i] = static_cast<u16>(v > 0xffffu ? 0xffffu : v);      // saturate: anything >= 65536 is illegal anyway
+            v = v + 1 + (v >> 5);
+        }
+    }
+};
+__device__ const ProbeTableW g_probe_w{};
+
+constexpr u32 crc_step32_w(u32 x)
+{
+    for (int k = 0; k < 32; ++k) x = (x >> 1) ^ ((x & 1u) ? 0x82F63B78u : 0u);
+    return x;
+}
+// The CRC step is GF(2)-linear: step32(b) = XOR over the four bytes of LUT[k][byte k]   (HashTable.cs:109-112)
+struct CrcLutW {
+    u16 v[1024];
+    constexpr CrcLutW() : v{}
+    {
+        for (int k = 0; k < 4; ++k)
+            for (int b = 0; b < 256; ++b) v[k * 256 + b] = static_cast<u16>(crc_step32_w(static_cast<u32>(b) << (8 * k)) & 0xffffu);
+    }
+};
+__device__ const CrcLutW g_crc_lut_w{};
+
+__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }   // DS ops of one wave execute in order; compiler-only
+__device__ __forceinline__ u32 log2_floor_w(u32 v) { return 31u - __clz(v); }
+
+struct __attribute__((packed)) snp_u16_unaligned_w { u16 v; };
+
+// HashTable.TableEntry (HashTable.cs:91-126) -> entry index.  hmask = step32(mask) & 0xffff.
+template <int VARIANT>
+__device__ __forceinline__ u32 bucket_of(u32 bytes, u32 mask, u32 hmask, const u16* lut)
+{
+    u32 hash;
+    if constexpr (VARIANT == SNP_HASH_CRC32C) {
+        hash = lut[bytes & 0xffu] ^ lut[256 + ((bytes >> 8) & 0xffu)] ^ lut[512 + ((bytes >> 16) & 0xffu)] ^ lut[768 + (bytes >> 24)] ^ hmask;
+    } else {
+        hash = (0x1e35a7bdu * bytes) >> 17;
+    }
+    return (hash & mask) >> 1;
+}
+
+// number of leading equal bytes of two 16-byte pieces (0..16)
+__device__ __forceinline__ u32 common16(const snp_u128_unaligned& a, const snp_u128_unaligned& b)
+{
+    const u32 x0 = a.v[0] ^ b.v[0], x1 = a.v[1] ^ b.v[1], x2 = a.v[2] ^ b.v[2], x3 = a.v[3] ^ b.v[3];
+    const u32 xd = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3;
+    const u32 base = x0 ? 0u : x1 ? 4u : x2 ? 8u : 12u;
+    return xd ? base + (static_cast<u32>(__builtin_ctz(xd)) >> 3) : 16u;
+}
+
+// FindMatchLength (:562-688) by the whole wave: src[cand..] vs src[p..], the first `known` bytes are known equal.
+// 4 bytes per lane per step; the fragment's last bytes are compared bytewise.  Returns the total match length.
+__device__ __forceinline__ u32 wave_match_extend(const u8* src, u32 n, u32 p, u32 cand, u32 known, u32 lane)
+{
+    u32 base = known;
+    for (;;) {
+        const u32 o = base + 4 * lane;
+        const u32 at = p + o;
+        const u32 avail = at < n ? (n - at < 4 ? n - at : 4u) : 0u;
+        u32 x = 0, y = 0;
+        if (avail == 4) {
+            x = ld32u(src + at);
+            y = ld32u(src + cand + o);
+        } else {
+            for (u32 k = 0; k < avail; ++k) {
+                x |= static_cast<u32>(src[at + k]) << (8 * k);
+                y |= static_cast<u32>(src[cand + o + k]) << (8 * k);
+            }
+        }
+        const u32 d = x ^ y;
+        u32 eq = d ? static_cast<u32>(__builtin_ctz(d)) >> 3 : 4u;
+        eq = eq < avail ? eq : avail;
+        const u64 nf = ballot64(eq != 4);
+        if (nf) {
+            const u32 fl = static_cast<u32>(__builtin_ctzll(nf));
+            return base + 4 * fl + read_lane(eq, fl);
+        }
+        base += 256;
+    }
+}
+
+// One lane copies len (1..64) bytes, exact stores; reads 16 bytes at s when len < 16 (caller guarantees they exist).
+__device__ __forceinline__ void lane_copy_w(u8* d, const u8* s, u32 len)
+{
+    const snp_u128_unaligned p0 = *reinterpret_cast<const snp_u128_unaligned*>(s);
+    if (len >= 16) {
+        snp_u128_unaligned p1 = p0;
+        if (len > 16) p1 = *reinterpret_cast<const snp_u128_unaligned*>(s + len - 16);
+        *reinterpret_cast<snp_u128_unaligned*>(d) = p0;
+        if (len > 16) *reinterpret_cast<snp_u128_unaligned*>(d + len - 16) = p1;
+        if (len > 32) {
+            *reinterpret_cast<snp_u128_unaligned*>(d + 16) = *reinterpret_cast<const snp_u128_unaligned*>(s + 16);
+            if (len > 48) *reinterpret_cast<snp_u128_unaligned*>(d + 32) = *reinterpret_cast<const snp_u128_unaligned*>(s + 32);
+        }
+    } else {
+        const bool c8 = (len & 8u) != 0, c4 = (len & 4u) != 0, c2 = (len & 2u) != 0;
+        const u32 a0 = c8 ? p0.v[2] : p0.v[0];
+        const u32 a1 = c8 ? p0.v[3] : p0.v[1];
+        const u32 b0 = c4 ? a1 : a0;
+        const u32 c0 = c2 ? b0 >> 16 : b0;
+        const u32 o4 = len & 8u, o2 = len & 12u, o1 = len & 14u;
+        if (c8) reinterpret_cast<snp_u64_unaligned*>(d)->v = p0.v[0] | (static_cast<u64>(p0.v[1]) << 32);
+        if (c4) st32u(d + o4, a0);
+        if (c2) reinterpret_cast<snp_u16_unaligned_w*>(d + o2)->v = static_cast<u16>(b0);
+        if (len & 1u) d[o1] = static_cast<u8>(c0);
+    }
+}
+
+// Inclusive prefix sum across the 64 lanes with DPP row shifts / row broadcasts.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_or_zero_w(u32 v)
+{
+    return static_cast<u32>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ u32 wave_inclusive_scan_w(u32 x)
+{
+    u32 y = x + dpp_or_zero_w<0x111, 0xf>(x);
+    y += dpp_or_zero_w<0x112, 0xf>(x);
+    y += dpp_or_zero_w<0x113, 0xf>(x);
+    y += dpp_or_zero_w<0x114, 0xf>(y);
+    y += dpp_or_zero_w<0x118, 0xf>(y);
+    y += dpp_or_zero_w<0x142, 0xa>(y);
+    y += dpp_or_zero_w<0x143, 0xc>(y);
+    return y;
+}
+
+// EmitLiteral of a long run by the whole wave (:418-464): tag (+ length bytes) by the first lanes, body 16 B per lane.
+__device__ __forceinline__ u32 wave_emit_literal(u8* dst, u32 op, const u8* src, u32 s, u32 len, u32 lane)
+{
+    const u32 k = len - 1;
+    u32 hdr;
+    if (k < 60) {
+        if (lane == 0) dst[op] = static_cast<u8>(k << 2);
+        hdr = 1;
+    } else {
+        const u32 count = (log2_floor_w(k) >> 3) + 1;                   // :447
+        if (lane == 0) dst[op] = static_cast<u8>((59 + count) << 2);    // :451
+        if (lane >= 1 && lane <= count) dst[op + lane] = static_cast<u8>(k >> (8 * (lane - 1)));
+        hdr = 1 + count;
+    }
+    wave_copy(dst + op + hdr, src + s, len, lane);
+    return op + hdr + len;
+}
+
+// ---- multiword bit masks over the window (wave-uniform) ------------------------------------------------------
+template <int NP>
+struct WMask {
+    u64 w[NP];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) w[k] = 0;
+    }
+    // set bits a..b inclusive (a <= b < 64*NP)
+    __device__ __forceinline__ void set_range(u32 a, u32 b)
+    {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const u32 base = 64u * k;
+            if (a < base + 64 && b >= base) {
+                const u32 lo = a > base ? a - base : 0u;
+                const u32 hi = b < base + 63 ? b - base : 63u;
+                const u64 m = (~0ull << lo) & (~0ull >> (63u - hi));
+                w[k] |= m;
+            }
+        }
+    }
+    __device__ __forceinline__ void set_bit(u32 a)
+    {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if ((a >> 6) == static_cast<u32>(k)) w[k] |= 1ull << (a & 63u);
+    }
+    __device__ __forceinline__ bool test(u32 a) const
+    {
+        bool r = false;
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if ((a >> 6) == static_cast<u32>(k)) r = (w[k] >> (a & 63u)) & 1ull;
+        return r;
+    }
+    // first set bit in [a, b], kNone if there is none
+    __device__ __forceinline__ u32 first_in(u32 a, u32 b) const
+    {
+        u32 r = kNone;
+#pragma unroll
+        for (int k = NP - 1; k >= 0; --k) {
+            const u32 base = 64u * k;
+            if (a < base + 64 && b >= base) {
+                const u32 lo = a > base ? a - base : 0u;
+                const u64 x = w[k] & (~0ull << lo);
+                if (x) {
+                    const u32 t = base + static_cast<u32>(__builtin_ctzll(x));
+                    if (t <= b) r = t;
+                }
+            }
+        }
+        return r;
+    }
+};
+
+template <int NP>
+__device__ __forceinline__ u32 read_half(const u32 (&v)[NP], u32 q)
+{
+    u32 r = 0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+        if ((q >> 6) == static_cast<u32>(k)) r = read_lane(v[k], q & 63u);
+    return r;
+}
+
+struct ParseState {
+    u32 S, pos, kb;        // kb: pos == S + D[kb] whenever pos >= S
+    bool pend, done;
+};
+
+#if SNP_W_PROF
+__device__ unsigned long long g_wprof[16];
+#define WPROF_ADD(k, v) do { if (lane == 0) atomicAdd(&g_wprof[k], static_cast<unsigned long long>(v)); } while (0)
+#else
+#define WPROF_ADD(k, v)
+#endif
+
+template <int VARIANT, int NP>
+__global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                          const u32* __restrict__ in_len, u32 nblocks,
+                                                          u8* __restrict__ out, const u64* __restrict__ out_off,
+                                                          u32* __restrict__ out_len, i32* __restrict__ status,
+                                                          int emit_varint)
+{
+    constexpr u32 W = 64u * NP;
+    __shared__ u16 table[16384];                                        // HashTable.cs:17-18
+    __shared__ u16 lut[VARIANT == SNP_HASH_CRC32C ? 1024 : 8];
+    __shared__ u64 ring[128];                                           // tokens: position | length << 16 | offset << 32
+
+    const u32 b = blockIdx.x;
+    if (b >= nblocks) return;
+    const u32 lane = lane_id();
+    const u8* src = in + in_off[b];
+    const u32 n = bcast_first(in_len[b]);
+    u8* dst = out + out_off[b];
+    if (n > SNP_BLOCK_SIZE) {
+        if (lane == 0) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; }
+        return;
+    }
+
+    u32 op = 0;
+    if (emit_varint) {                                                  // VarIntEncoding.TryWrite  VarIntEncoding.Write.cs:5-79
+        const u32 hb = n < (1u << 7) ? 1 : n < (1u << 14) ? 2 : 3;
+        if (lane < hb) dst[lane] = static_cast<u8>((n >> (7 * lane)) | (lane + 1 < hb ? 0x80u : 0u));
+        op = hb;
+    }
+
+    u32 eprev = 0;            // input position up to which output has been produced
+    if (n >= 15) {                                                      // Constants.InputMarginBytes  :190
+        const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << log2_floor_w(n - 1));   // HashTable.cs:57-71
+        const u32 mask = 2 * (tsize - 1);                               // :181
+        for (u32 i = lane * 8; i < tsize; i += 64 * 8) *reinterpret_cast<uint4*>(&table[i]) = make_uint4(0, 0, 0, 0);
+        u32 hmask = 0;
+        if constexpr (VARIANT == SNP_HASH_CRC32C) {
+            for (u32 i = lane; i < 1024; i += 64) lut[i] = g_crc_lut_w.v[i];
+            hmask = crc_step32_w(mask) & 0xffffu;
+        }
+        lds_fence();
+        const u32 limit = n - 15;                                       // :192
+
+        ParseState st{1u, 1u, 0u, false, false};
+        u32 head = 0, cnt = 0;                                          // token ring
+
+        // ---- emission of `nb` queued tokens, one per lane ------------------------------------------------------
+        auto emit_batch = [&](u32 nb) {
+            const bool act = lane < nb;
+            const u64 tk = act ? ring[(head + lane) & 127u] : 0ull;
+            const u32 t = static_cast<u32>(tk) & 0xffffu, len = static_cast<u32>(tk >> 16) & 0xffffu, off = static_cast<u32>(tk >> 32) & 0xffffu;
+            const u32 endp = t + len;
+            u32 prev = static_cast<u32>(__shfl_up(static_cast<int>(endp), 1));
+            if (lane == 0) prev = eprev;
+            const u32 ll = act ? t - prev : 0u;                         // literal before this copy (may be empty)
+            const u32 k = ll - 1;
+            const u32 lh = ll == 0 ? 0u : k < 60 ? 1u : k < 256 ? 2u : 3u;
+            // EmitCopy in closed form (:507-543): q tags of 64, optionally one of 60, then the final 4..64-byte tag
+            const u32 q = len >= 68 ? (len - 4) >> 6 : 0u;
+            u32 r = len - (q << 6);
+            const bool c60 = r > 64;
+            if (c60) r -= 60;
+            const bool one = r < 12 && off < 2048;
+            const u32 csz = 3 * q + (c60 ? 3u : 0u) + (one ? 2u : 3u);
+            const u32 sz = act ? lh + ll + csz : 0u;
+            const u32 incl = wave_inclusive_scan_w(sz);
+            const u32 total = read_lane(incl, 63);
+            u8* o = dst + op + (incl - sz);
+            // literal
+            const u64 big = ballot64(act && ll > 64);
+            if (act && ll) {
+                if (k < 60) o[0] = static_cast<u8>(k << 2);
+                else if (k < 256) { o[0] = static_cast<u8>(60u << 2); o[1] = static_cast<u8>(k); }
+                else { o[0] = static_cast<u8>(61u << 2); o[1] = static_cast<u8>(k); o[2] = static_cast<u8>(k >> 8); }
+                if (ll <= 64) {
+                    if (prev + 16 <= n) lane_copy_w(o + lh, src + prev, ll);
+                    else for (u32 i = 0; i < ll; ++i) o[lh + i] = src[prev + i];
+                }
+            }
+            // copy tags
+            if (act) {
+                u8* c = o + lh + ll;
+                for (u32 i = 0; i < q; ++i) { c[0] = static_cast<u8>(2u | (63u << 2)); c[1] = static_cast<u8>(off); c[2] = static_cast<u8>(off >> 8); c += 3; }
+                if (c60) { c[0] = static_cast<u8>(2u | (59u << 2)); c[1] = static_cast<u8>(off); c[2] = static_cast<u8>(off >> 8); c += 3; }
+                if (one) { c[0] = static_cast<u8>(1u | ((r - 4) << 2) | ((off >> 8) << 5)); c[1] = static_cast<u8>(off); }
+                else { c[0] = static_cast<u8>(2u | ((r - 1) << 2)); c[1] = static_cast<u8>(off); c[2] = static_cast<u8>(off >> 8); }
+            }
+            // literals longer than 64 bytes: whole-wave copies
+            u64 bg = big;
+            while (bg) {
+                const u32 f = static_cast<u32>(__builtin_ctzll(bg));
+                bg &= bg - 1;
+                const u32 f_o = read_lane(incl - sz, f) + read_lane(lh, f);
+                wave_copy(dst + op + f_o, src + read_lane(prev, f), read_lane(ll, f), lane);
+            }
+            op += total;
+            eprev = read_lane(endp, nb - 1);
+            head = (head + nb) & 127u;
+            cnt -= nb;
+        };
+
+        while (!st.done) {
+            st.S = bcast_first(st.S); st.pos = bcast_first(st.pos); st.kb = bcast_first(st.kb);
+            st.pend = bcast_first(st.pend ? 1u : 0u) != 0;
+            op = bcast_first(op); eprev = bcast_first(eprev); head = bcast_first(head); cnt = bcast_first(cnt);
+            const u32 w = st.pos - (st.pend ? 1u : 0u);
+            const bool zone1 = (st.pos + 1 == st.S) || (st.pos - st.S <= 32);
+            u32 cut0 = 0;
+            if (w + 17 <= n) { cut0 = n - 16 - w; if (cut0 > W) cut0 = W; }   // positions p with p + 17 <= n
+            if (zone1 && cut0 >= 16) {
+                // ================================ dense round ================================================
+                WPROF_ADD(0, 1);
+                snp_u128_unaligned X[NP];
+                u32 pp[NP], h[NP], c[NP], m[NP];
+                bool valid[NP], hit[NP], unres[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const u32 q = 64u * k + lane;
+                    pp[k] = w + q;
+                    valid[k] = q < cut0;
+                    if (valid[k]) X[k] = *reinterpret_cast<const snp_u128_unaligned*>(src + pp[k]);
+                    else X[k].v[0] = X[k].v[1] = X[k].v[2] = X[k].v[3] = 0;
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) h[k] = bucket_of<VARIANT>(X[k].v[0], mask, hmask, lut);
+                lds_fence();
+#pragma unroll
+                for (int k = 0; k < NP; ++k) c[k] = table[h[k]];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    m[k] = 0;
+                    if (valid[k]) {
+                        const snp_u128_unaligned E = *reinterpret_cast<const snp_u128_unaligned*>(src + c[k]);
+                        m[k] = common16(X[k], E);
+                    }
+                    hit[k] = valid[k] && m[k] >= 4;
+                    unres[k] = hit[k] && m[k] == 16;
+                }
+                // per-lane extension up to kCap bytes
+                for (u32 k16 = 16; k16 < kCap; k16 += 16) {
+                    bool any = false;
+                    bool go[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) { go[k] = unres[k] && pp[k] + k16 + 16 <= n; any = any || go[k]; }
+                    if (!ballot64(any)) break;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        if (go[k]) {
+                            const snp_u128_unaligned A = *reinterpret_cast<const snp_u128_unaligned*>(src + pp[k] + k16);
+                            const snp_u128_unaligned E = *reinterpret_cast<const snp_u128_unaligned*>(src + c[k] + k16);
+                            const u32 mm = common16(A, E);
+                            m[k] += mm;
+                            unres[k] = mm == 16;
+                        }
+                }
+                WMask<NP> HITM, UNRES;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) { HITM.w[k] = ballot64(hit[k]); UNRES.w[k] = ballot64(unres[k]); }
+
+                // ---- scalar walk over [o, cut): visited probes V, ip-1 inserts INS, end state ---------------------
+                WMask<NP> V, INS;
+                ParseState e;
+                auto walk = [&](u32 cut) {
+                    V.clear();
+                    INS.clear();
+                    e = st;
+                    u32 o = st.pos - w;
+                    if (st.pend) { INS.w[0] |= 1ull; e.pend = false; }
+                    for (;;) {
+                        if (o >= cut) { e.pos = w + o; e.kb = e.pos >= e.S ? e.pos - e.S : 0u; return; }
+                        const u32 zone_end = e.S + 32 - w;             // last stride-1 position of this scan
+                        const u32 lim = zone_end < cut - 1 ? zone_end : cut - 1;
+                        const u32 t = HITM.first_in(o, lim);
+                        if (t == kNone) {
+                            V.set_range(o, lim);
+                            if (lim == zone_end) { e.pos = e.S + 34; e.kb = 33; }        // probe 33 is two bytes further (:319-320)
+                            else { e.pos = w + cut; e.kb = e.pos - e.S; }
+                            return;
+                        }
+                        V.set_range(o, t);
+                        u32 ml = read_half<NP>(m, t);
+                        if (UNRES.test(t)) {
+                            WPROF_ADD(3, 1);
+                            ml = wave_match_extend(src, n, w + t, read_half<NP>(c, t), ml, lane);
+#pragma unroll
+                            for (int k = 0; k < NP; ++k) {
+                                if (64u * k + lane == t) m[k] = ml;
+                                if ((t >> 6) == static_cast<u32>(k)) UNRES.w[k] &= ~(1ull << (t & 63u));
+                            }
+                        }
+                        const u32 ip = w + t + ml;
+                        if (ip >= limit) { e.done = true; e.pos = ip; return; }          // :381-384
+                        e.S = ip + 1;
+                        e.pos = ip;
+                        e.kb = 0;
+                        if (t + ml - 1 < cut) INS.set_bit(t + ml - 1);
+                        else { e.pend = true; return; }
+                        o = t + ml;
+                    }
+                };
+                walk(cut0);
+                // ---- publish, read back: pairwise distinct buckets? ----------------------------------------------------
+                bool pub[NP];
+                u32 rb[NP];
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    pub[k] = ((V.w[k] | INS.w[k]) >> lane) & 1ull;
+                    if (pub[k]) table[h[k]] = static_cast<u16>(pp[k]);
+                }
+                lds_fence();
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    rb[k] = pub[k] ? static_cast<u32>(table[h[k]]) : pp[k];
+                    bad = bad || rb[k] != pp[k];
+                }
+                if (ballot64(bad)) {
+                    WPROF_ADD(1, 1);
+                    // min-position-wins: afterwards every later duplicate reads a smaller position than its own
+                    for (;;) {
+                        bool again = false;
+#pragma unroll
+                        for (int k = 0; k < NP; ++k)
+                            if (pub[k] && rb[k] > pp[k]) { table[h[k]] = static_cast<u16>(pp[k]); again = true; }
+                        if (!ballot64(again)) break;
+                        lds_fence();
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) rb[k] = pub[k] ? static_cast<u32>(table[h[k]]) : pp[k];
+                    }
+                    u32 q2 = kNone;
+#pragma unroll
+                    for (int k = NP - 1; k >= 0; --k) {
+                        const u64 los = ballot64(pub[k] && rb[k] < pp[k]);
+                        if (los) q2 = 64u * k + static_cast<u32>(__builtin_ctzll(los));
+                    }
+                    // roll the table back, re-walk the prefix, publish it (distinct buckets by minimality of q2)
+                    lds_fence();
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        if (pub[k]) table[h[k]] = static_cast<u16>(c[k]);
+                    lds_fence();
+                    walk(q2);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        pub[k] = ((V.w[k] | INS.w[k]) >> lane) & 1ull;
+                        if (pub[k]) table[h[k]] = static_cast<u16>(pp[k]);
+                    }
+                    lds_fence();
+                }
+                // ---- queue the tokens of the accepted prefix ------------------------------------------------------
+                u32 pushed = 0;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const u64 tm = V.w[k] & HITM.w[k];
+                    if ((tm >> lane) & 1ull) {
+                        const u32 idx = cnt + pushed + static_cast<u32>(__builtin_popcountll(tm & lanes_below(lane)));
+                        ring[(head + idx) & 127u] = static_cast<u64>(pp[k]) | (static_cast<u64>(m[k]) << 16) | (static_cast<u64>(pp[k] - c[k]) << 32);
+                    }
+                    pushed += static_cast<u32>(__builtin_popcountll(tm));
+                }
+                WPROF_ADD(2, pushed);
+                cnt += pushed;
+                st = e;
+                lds_fence();
+            } else {
+                // ================================ sparse round ===============================================
+                WPROF_ADD(4, 1);
+                const u32 sh = st.pend ? 1u : 0u;
+                const bool postcopy = st.pos + 1 == st.S;
+                const bool is_ins = st.pend && lane == 0;
+                const u32 i = lane - sh;                                // probe slot (lanes >= sh)
+                u32 kidx, p, nxt;
+                bool legal;
+                if (is_ins) { kidx = 0; p = st.pos - 1; nxt = st.pos; legal = true; }
+                else if (postcopy) {
+                    if (i == 0) { kidx = 0; p = st.S - 1; nxt = st.S; legal = true; }
+                    else {
+                        kidx = i - 1;
+                        p = st.S + g_probe_w.d[kidx];
+                        nxt = st.S + g_probe_w.d[kidx + 1];
+                        legal = nxt <= limit;
+                    }
+                } else {
+                    kidx = st.kb + i;
+                    kidx = kidx < 702 ? kidx : 702u;
+                    p = st.S + g_probe_w.d[kidx];
+                    nxt = st.S + g_probe_w.d[kidx + 1];
+                    legal = nxt <= limit;
+                }
+                const u32 d = legal ? ld32u(src + p) : 0u;
+                const u32 h = bucket_of<VARIANT>(d, mask, hmask, lut);
+                lds_fence();
+                const u32 c = table[h];
+                const u32 ev = (legal && !is_ins) ? ld32u(src + c) : ~d;
+                const bool hitl = legal && !is_ins && ev == d;
+                const u64 lmask = ballot64(legal);
+                const u64 stop = ballot64(hitl) | ~lmask;
+                const u32 first0 = stop ? static_cast<u32>(__builtin_ctzll(stop)) : 64u;
+                const bool is_hit = first0 < 64 && ((lmask >> first0) & 1ull);
+                const bool terminated = first0 < 64 && !is_hit;
+                u32 last = is_hit ? first0 + 1 : first0;                // slots [0, last) are this round's events
+                // publish / read back / cut
+                bool pub = lane < last;
+                if (pub) table[h] = static_cast<u16>(p);
+                lds_fence();
+                u32 rb = pub ? static_cast<u32>(table[h]) : p;
+                bool cut = false;
+                if (ballot64(rb != p)) {
+                    WPROF_ADD(5, 1);
+                    for (;;) {
+                        const bool again = pub && rb > p;
+                        if (again) table[h] = static_cast<u16>(p);
+                        if (!ballot64(again)) break;
+                        lds_fence();
+                        rb = pub ? static_cast<u32>(table[h]) : p;
+                    }
+                    const u64 los = ballot64(pub && rb < p);
+                    const u32 q2 = static_cast<u32>(__builtin_ctzll(los));   // los != 0: some lane lost to an earlier one
+                    lds_fence();
+                    if (pub) table[h] = static_cast<u16>(c);
+                    lds_fence();
+                    last = q2;
+                    cut = true;
+                    pub = lane < last;
+                    if (pub) table[h] = static_cast<u16>(p);
+                    lds_fence();
+                }
+                if (cut) {
+                    // resume at slot `last` (>= 1): its position becomes pos
+                    st.pend = false;
+                    if (postcopy && last == sh) { /* the post-copy probe itself: pos stays S-1 */ }
+                    else { st.pos = read_lane(p, last); st.kb = read_lane(kidx, last); }
+                } else if (is_hit) {
+                    const u32 t = read_lane(p, first0), cd = read_lane(c, first0);
+                    const u32 ml = wave_match_extend(src, n, t, cd, 4, lane);
+                    if (lane == 0) ring[(head + cnt) & 127u] = static_cast<u64>(t) | (static_cast<u64>(ml) << 16) | (static_cast<u64>(t - cd) << 32);
+                    cnt += 1;
+                    WPROF_ADD(2, 1);
+                    const u32 ip = t + ml;
+                    st.pend = false;
+                    if (ip >= limit) { st.done = true; st.pos = ip; }
+                    else { st.S = ip + 1; st.pos = ip; st.kb = 0; st.pend = true; }
+                } else if (terminated) {
+                    st.done = true;
+                } else {
+                    st.pend = false;
+                    st.pos = read_lane(nxt, 63);
+                    st.kb = read_lane(kidx, 63) + 1;
+                }
+                lds_fence();
+            }
+            if (cnt >= 64) emit_batch(64);
+        }
+        if (cnt) emit_batch(cnt);
+    }
+    if (eprev < n) op = wave_emit_literal(dst, op, src, eprev, n - eprev, lane);   // emit_remainder  :406-411
+
+    if (lane == 0) {
+        out_len[b] = op;
+        status[b] = SNP_OK;
+    }
+}
+
+}  // namespace
+
+#if SNP_W_PROF
+extern "C" int snp_debug_read_wprof(unsigned long long* out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wprof), sizeof(g_wprof));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_wprof), z, sizeof(z));
+    }
+    return static_cast<int>(e);
+}
+#endif
+
+extern "C" hipError_t snp_launch_compress_win(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
+                                              const u64* out_off, u32* out_len, i32* status, int variant,
+                                              int emit_varint, int np, hipStream_t stream)
+{
+    if (nblocks == 0) return hipSuccess;
+#define SNP_LAUNCH_W(V, P)                                                                                            \
+    hipLaunchKernelGGL((k_compress_win<V, P>), dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, \
+                       out, out_off, out_len, status, emit_varint)
+    if (variant == SNP_HASH_CRC32C) {
+        if (np == 1) SNP_LAUNCH_W(SNP_HASH_CRC32C, 1); else SNP_LAUNCH_W(SNP_HASH_CRC32C, 2);
+    } else {
+        if (np == 1) SNP_LAUNCH_W(SNP_HASH_MUL, 1); else SNP_LAUNCH_W(SNP_HASH_MUL, 2);
+    }
+#undef SNP_LAUNCH_W
+    return hipGetLastError();
+}
