@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q -x -k "(layouts and win) or (fuzz_compress and win)" > gpurun_out/r2v3_pytest.log 2>&1
+tail -3 gpurun_out/r2v3_pytest.log
+for np in 1 2; do
+SNAPPIER_HIP_LIB=$PWD/snappier_amd/variants/libsnappier_hip_wprof2.so NP=$np DATA=html BLOCKS=4096 timeout 120 python scripts/prof_compress_win.py 2>&1 | tail -1 | tee -a gpurun_out/r2v3_prof.jsonl
+SNAPPIER_HIP_COMPRESS=win SNAPPIER_HIP_WIN_NP=$np timeout 300 python scripts/time_compress.py ${NB:-32768} 2>&1 | tail -1 | tee -a gpurun_out/r2v3_time.jsonl
+done

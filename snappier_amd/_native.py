@@ -26,7 +26,8 @@ MAX_BLOCK_COMPRESSED = 76491
 
 def declared_symbols() -> list[str]:
     """Every function name declared in include/snappier_hip.h."""
-    text = open(HEADER_PATH).read()
+    with open(HEADER_PATH) as f:
+        text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(snp_[a-z0-9_]+)\s*\(", text)))
 
@@ -42,7 +43,9 @@ def lib() -> C.CDLL:
         raise ImportError(f"{LIB_PATH} is missing: build it with `python snappier_amd/build.py` "
                           "(there is no CPU fallback for the codec)")
     L = C.CDLL(LIB_PATH)
-    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    # every symbol the header declares must be exported; an installed copy without the repo's include/ directory
+    # falls back to the signatures bound below (a missing one still raises AttributeError there)
+    missing = [s for s in declared_symbols() if not hasattr(L, s)] if os.path.exists(HEADER_PATH) else []
     if missing:
         raise ImportError(f"libsnappier_hip.so does not export: {missing}")
     vp, sz, u32, u64, i32, i64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_int64

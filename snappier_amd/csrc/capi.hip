@@ -64,7 +64,8 @@ struct snp_ctx {
     u32 par_min = 4 * SNP_BLOCK_SIZE;   // single blocks at least this long are decoded one wavefront per 64 KiB fragment (0 = never)
     int compress_mode = 0;   // 0 auto, 1 wave-per-fragment single-token rounds (compress.hip), 2 fragment-per-lane with HBM tables
                              // (compress_lanes.hip), 3 wave-per-fragment multi-token windows (compress_win.hip)
-    int win_np = 2;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2)
+    int win_np = 1;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2; 2 measured slower)
+    u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
     DevBuf in, out, meta, work, tables;
     uint64_t counters[2] = {0, 0};   // snp_ctx_counter
     std::string err;
@@ -85,10 +86,14 @@ struct snp_ctx {
     bool launch_compress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
                          u32* out_len, i32* status, int emit_varint)
     {
-        if (compress_mode == 3 || compress_mode == 0)
+        // Measured on MI355X (profiles/r02_compress_layouts.jsonl): the window kernel (LDS tables, 1024 fragments in flight)
+        // runs at the same rate at any batch size and beats the single-token wave kernel everywhere; the lane kernel (HBM
+        // tables) needs >= 16 384 fragments in flight before its memory-level parallelism overtakes it.
+        const bool win = compress_mode == 3 || (compress_mode == 0 && nblocks < win_max);
+        if (win)
             return check(snp_launch_compress_win(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
                                                  emit_varint, win_np, stream), "compress (windows) launch");
-        const bool lanes = compress_mode == 2;
+        const bool lanes = compress_mode == 2 || compress_mode == 0;
         if (!lanes)
             return check(snp_launch_compress(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
                                              emit_varint, stream), "compress launch");
@@ -156,6 +161,28 @@ struct snp_ctx {
         return true;
     }
     bool use_device() { return check(hipSetDevice(device), "hipSetDevice"); }
+    // The context's scratch (hash tables, staging) is ordered by the stream it runs on.  Moving the context to another
+    // stream: everything already queued on the old stream must finish before the new stream touches the scratch.
+    bool rebind(hipStream_t next)
+    {
+        if (next == stream) return true;
+        if (!order_ev && !check(hipEventCreateWithFlags(&order_ev, hipEventDisableTiming), "hipEventCreate")) return false;
+        return check(hipEventRecord(order_ev, stream), "hipEventRecord") &&
+               check(hipStreamWaitEvent(next, order_ev, 0), "hipStreamWaitEvent");
+    }
+    hipEvent_t order_ev = nullptr;
+};
+
+// Entry points run on the context's device and leave the caller's current device as they found it.
+struct DevGuard {
+    int prev = -1, dev = -1;
+    bool ok = false;
+    explicit DevGuard(snp_ctx* c) : dev(c->device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = prev == dev || c->use_device();
+    }
+    ~DevGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
 };
 
 extern "C" {
@@ -172,7 +199,8 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     if (!c) return SNP_ERR_DEVICE;
     c->device = device;
     c->variant = hash_variant;
-    if (hipSetDevice(device) != hipSuccess) { delete c; return SNP_ERR_DEVICE; }
+    DevGuard dg(c);
+    if (!dg.ok) { delete c; return SNP_ERR_DEVICE; }
     if (stream) c->stream = static_cast<hipStream_t>(stream);
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SNP_ERR_DEVICE; }
@@ -193,7 +221,9 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
     c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : (cm && strncmp(cm, "win", 3) == 0) ? 3 : 0;
     const char* wn = getenv("SNAPPIER_HIP_WIN_NP");
-    if (wn) c->win_np = atoi(wn) == 1 ? 1 : 2;
+    if (wn) c->win_np = atoi(wn) == 2 ? 2 : 1;
+    const char* wm = getenv("SNAPPIER_HIP_WIN_MAX");
+    if (wm) c->win_max = static_cast<u32>(strtoul(wm, nullptr, 10));
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
     // fragments decoded in parallel (tag_index.hip); 0 = always one wavefront per block
     const char* tt = getenv("SNAPPIER_HIP_TABLE_TRIES");
@@ -209,24 +239,31 @@ uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 
 void snp_ctx_destroy(snp_ctx* c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables})
-        if (b->p) (void)hipFree(b->p);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    {
+        DevGuard dg(c);
+        (void)hipStreamSynchronize(c->stream);
+        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables})
+            if (b->p) (void)hipFree(b->p);
+        if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    }
     delete c;
 }
 
 snp_status snp_ctx_set_stream(snp_ctx* c, void* stream)
 {
     if (!c) return SNP_ERR_BAD_ARG;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
+    hipStream_t next = static_cast<hipStream_t>(stream);
     if (c->own_stream) {
-        (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
         c->own_stream = false;
+    } else if (!c->rebind(next)) {
+        return SNP_ERR_DEVICE;
     }
-    c->stream = static_cast<hipStream_t>(stream);
+    c->stream = next;
     return SNP_OK;
 }
 
@@ -310,7 +347,8 @@ snp_status snp_compress_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_
                               int32_t* status)
 {
     if (!c || (nblocks && (!in || !in_off || !in_len || !out || !out_off || !out_len || !status))) return SNP_ERR_BAD_ARG;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     return c->launch_compress(in, in_off, in_len, nblocks, out, out_off, out_len, status, 1) ? SNP_OK : SNP_ERR_DEVICE;
 }
 
@@ -320,7 +358,8 @@ snp_status snp_decompress_batch(snp_ctx* c, const uint8_t* in, const uint64_t* i
 {
     if (!c || (nblocks && (!in || !in_off || !in_len || !out || !out_off || !out_cap || !out_len || !status)))
         return SNP_ERR_BAD_ARG;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     return c->launch_decompress(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, nullptr) ? SNP_OK
                                                                                                               : SNP_ERR_DEVICE;
 }
@@ -329,7 +368,8 @@ snp_status snp_crc32c_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_of
                             uint32_t nblocks, int masked, uint32_t* out_crc)
 {
     if (!c || (nblocks && (!in || !in_off || !in_len || !out_crc))) return SNP_ERR_BAD_ARG;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     return c->check(snp_launch_crc32c(in, in_off, in_len, nblocks, masked, out_crc, nullptr, nullptr, c->stream),
                     "crc32c launch") ? SNP_OK : SNP_ERR_DEVICE;
 }
@@ -371,7 +411,8 @@ snp_status snp_frame_encode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, 
 {
     if (!c || !d_out || !d_written || !d_work || (n && !d_in)) return SNP_ERR_BAD_ARG;
     if (n > 0xffffffffull * SNP_BLOCK_SIZE) return SNP_ERR_BAD_ARG;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     if (cap < SNP_STREAM_HEADER_LEN) return SNP_ERR_OUTPUT_TOO_SMALL;
     const u32 nc = static_cast<u32>((n + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE);
     hipStream_t s = c->stream;
@@ -399,7 +440,8 @@ snp_status snp_frame_decode_chunks_device(snp_ctx* c, const uint8_t* d_in, const
     if (!c || (nchunks && (!d_in || !chunk_type || !body_off || !body_len || !chunk_crc || !d_out || !out_off ||
                            !out_cap || !out_len || !status)))
         return SNP_ERR_BAD_ARG;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     hipStream_t s = c->stream;
     bool ok = c->launch_decompress(d_in, body_off, body_len, nchunks, d_out, out_off, out_cap, out_len, status, chunk_type);
     // CRC over the produced bytes, compared with the chunk's stored masked CRC  (SnappyStreamDecompressor.cs:117-131)
@@ -420,7 +462,8 @@ snp_status snp_frame_decode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, 
                                    uint32_t max_chunks, void* d_work, uint64_t* d_result)
 {
     if (!c || !d_work || !d_result || (n && !d_in) || (cap && !d_out)) return SNP_ERR_BAD_ARG;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     hipStream_t s = c->stream;
     u64* hdr = static_cast<u64*>(d_work);
     u64* body_off = hdr + 8;
@@ -456,7 +499,8 @@ snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
     if (n > 0xffffffffull) return SNP_ERR_BAD_ARG;                       // SnappyCompressor.cs:88-91
     if (cap == 0) return SNP_ERR_OUTPUT_TOO_SMALL;                        // Snappy.cs:57-62
     if (ranges_overlap(in, n, out, cap)) return SNP_ERR_OVERLAP;          // SnappyCompressor.cs:27-30
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
 
     u8 hdr[SNP_VARINT_MAX];                                               // VarIntEncoding.TryWrite  :34-37
     u32 hb = 0;
@@ -511,8 +555,9 @@ snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* 
 {
     if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
     *written = 0;
-    if (n > 0xffffffffull) return SNP_ERR_BAD_ARG;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    if (n > 0x7fffffffull) return SNP_ERR_BAD_ARG;                        // the reference's spans are int-length
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     hipStream_t s = c->stream;
     const u32 cap32 = cap > 0x7fffffffull ? 0x7fffffffu : static_cast<u32>(cap);
     if (!c->ensure(c->in, n + 16, "hipMalloc(in)") || !c->ensure(c->out, static_cast<size_t>(cap32) + 16, "hipMalloc(out)") ||
@@ -613,7 +658,8 @@ snp_status snp_crc32c(snp_ctx* c, const uint8_t* in, size_t n, int masked, uint3
 {
     if (!c || !out_crc || (n && !in)) return SNP_ERR_BAD_ARG;
     if (n > 0xffffffffull) return SNP_ERR_BAD_ARG;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     hipStream_t s = c->stream;
     if (!c->ensure(c->in, n + 16, "hipMalloc(in)") || !c->ensure(c->meta, 64, "hipMalloc(meta)")) return SNP_ERR_DEVICE;
     struct Meta { u64 off; u32 len, crc; } h{0, static_cast<u32>(n), 0};
@@ -634,7 +680,8 @@ snp_status snp_frame_encode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
     if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
     *written = 0;
     if (ranges_overlap(in, n, out, cap)) return SNP_ERR_OVERLAP;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     hipStream_t s = c->stream;
     const u64 max_out = static_cast<u64>(snp_frame_max_encoded_length(static_cast<int64_t>(n)));
     const u64 wbytes = snp_frame_encode_workspace(n);
@@ -667,6 +714,7 @@ struct ChunkScan {
     u64 total = 0;
     snp_status tail = SNP_OK;   // error met after the chunks listed above (they are still decoded and checked first)
 };
+static inline u64 snp_max_expansion(u64 body_bytes) { return (body_bytes / 3 + 1) * 64; }
 static void scan_chunks(const u8* in, size_t n, ChunkScan& cs)
 {
     size_t ip = 0;
@@ -686,6 +734,9 @@ static void scan_chunks(const u8* in, size_t n, ChunkScan& cs)
                 return;
             }
             if (dec > 0x7fffffffu) { cs.tail = SNP_ERR_BAD_LENGTH; return; }
+            // No tag expands more than 3 bytes -> 64 (a copy-2 of length 64): a chunk that declares more than its body can
+            // possibly produce is "Incomplete Snappy block." whatever its tags say -- and must not size any allocation.
+            if (type == 0x00 && dec > snp_max_expansion(size - 4 - hb)) { cs.tail = SNP_ERR_INCOMPLETE; return; }
             cs.type.push_back(static_cast<u8>(type));
             cs.body_off.push_back(ip + 4);
             cs.body_len.push_back(size - 4);
@@ -714,7 +765,8 @@ snp_status snp_frame_decode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
 {
     if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
     *written = 0;
-    if (!c->use_device()) return SNP_ERR_DEVICE;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
     ChunkScan cs;
     scan_chunks(in, n, cs);
     const u32 nc = static_cast<u32>(cs.type.size());

@@ -29,15 +29,19 @@
 #include "snp_device.h"
 
 #ifndef SNP_W_CAP
-#define SNP_W_CAP 48      // bytes of match length a hit position resolves by itself (multiple of 16)
+#define SNP_W_CAP 32      // bytes of match length every window position resolves by itself (16 or 32: one or two 16-byte pieces)
 #endif
 #ifndef SNP_W_PROF
 #define SNP_W_PROF 0
+#endif
+#ifndef SNP_W_ASMWALK
+#define SNP_W_ASMWALK 1   // NP == 1: the walk's common case as a hand-written scalar loop
 #endif
 
 namespace {
 
 constexpr u32 kCap = SNP_W_CAP;
+constexpr int kPieces = SNP_W_CAP / 16;
 constexpr u32 kNone = 0xffffffffu;
 
 // ---- compile-time tables -----------------------------------------------------------------------------------
@@ -70,6 +74,10 @@ struct CrcLutW {
 };
 __device__ const CrcLutW g_crc_lut_w{};
 
+__device__ __forceinline__ u64 bcast_first64(u64 v)
+{
+    return (static_cast<u64>(bcast_first(static_cast<u32>(v >> 32))) << 32) | bcast_first(static_cast<u32>(v));
+}
 __device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }   // DS ops of one wave execute in order; compiler-only
 __device__ __forceinline__ u32 log2_floor_w(u32 v) { return 31u - __clz(v); }
 
@@ -191,71 +199,76 @@ __device__ __forceinline__ u32 wave_emit_literal(u8* dst, u32 op, const u8* src,
     return op + hdr + len;
 }
 
-// ---- multiword bit masks over the window (wave-uniform) ------------------------------------------------------
+// ---- bit masks over the window positions, NP words, wave-uniform ---------------------------------------------
+// first set bit at or above o (o < 64*NP); 64*NP if there is none
 template <int NP>
-struct WMask {
-    u64 w[NP];
-    __device__ __forceinline__ void clear()
-    {
+__device__ __forceinline__ u32 mask_first_from(const u64 (&w)[NP], u32 o)
+{
+    if constexpr (NP == 1) {
+        const u64 x = w[0] >> o;
+        return x ? o + static_cast<u32>(__builtin_ctzll(x)) : 64u;
+    } else {
+        u32 r = 64u * NP;
 #pragma unroll
-        for (int k = 0; k < NP; ++k) w[k] = 0;
-    }
-    // set bits a..b inclusive (a <= b < 64*NP)
-    __device__ __forceinline__ void set_range(u32 a, u32 b)
-    {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
+        for (int k = NP - 1; k >= 0; --k) {
             const u32 base = 64u * k;
-            if (a < base + 64 && b >= base) {
-                const u32 lo = a > base ? a - base : 0u;
-                const u32 hi = b < base + 63 ? b - base : 63u;
-                const u64 m = (~0ull << lo) & (~0ull >> (63u - hi));
-                w[k] |= m;
+            if (o < base + 64) {
+                const u64 x = o > base ? (w[k] >> (o - base)) << (o - base) : w[k];
+                if (x) r = base + static_cast<u32>(__builtin_ctzll(x));
             }
         }
+        return r;
     }
-    __device__ __forceinline__ void set_bit(u32 a)
-    {
+}
+template <int NP>
+__device__ __forceinline__ void mask_set_bit(u64 (&w)[NP], u32 a)
+{
+    if constexpr (NP == 1) w[0] |= 1ull << a;
+    else {
 #pragma unroll
         for (int k = 0; k < NP; ++k)
             if ((a >> 6) == static_cast<u32>(k)) w[k] |= 1ull << (a & 63u);
     }
-    __device__ __forceinline__ bool test(u32 a) const
-    {
+}
+template <int NP>
+__device__ __forceinline__ bool mask_test(const u64 (&w)[NP], u32 a)
+{
+    if constexpr (NP == 1) return (w[0] >> a) & 1ull;
+    else {
         bool r = false;
 #pragma unroll
         for (int k = 0; k < NP; ++k)
             if ((a >> 6) == static_cast<u32>(k)) r = (w[k] >> (a & 63u)) & 1ull;
         return r;
     }
-    // first set bit in [a, b], kNone if there is none
-    __device__ __forceinline__ u32 first_in(u32 a, u32 b) const
-    {
-        u32 r = kNone;
+}
+// set bits a..b inclusive; nothing if a > b; bits >= 64*NP are dropped
+template <int NP>
+__device__ __forceinline__ void mask_set_range(u64 (&w)[NP], u32 a, u32 b)
+{
+    if (a > b) return;
 #pragma unroll
-        for (int k = NP - 1; k >= 0; --k) {
-            const u32 base = 64u * k;
-            if (a < base + 64 && b >= base) {
-                const u32 lo = a > base ? a - base : 0u;
-                const u64 x = w[k] & (~0ull << lo);
-                if (x) {
-                    const u32 t = base + static_cast<u32>(__builtin_ctzll(x));
-                    if (t <= b) r = t;
-                }
-            }
+    for (int k = 0; k < NP; ++k) {
+        const u32 base = 64u * k;
+        if (a < base + 64 && b >= base) {
+            const u32 lo = a > base ? a - base : 0u;
+            const u32 hi = b - base < 63 ? b - base : 63u;
+            w[k] |= (~0ull << lo) & (~0ull >> (63u - hi));
         }
-        return r;
     }
-};
+}
 
 template <int NP>
 __device__ __forceinline__ u32 read_half(const u32 (&v)[NP], u32 q)
 {
-    u32 r = 0;
+    if constexpr (NP == 1) return read_lane(v[0], q);
+    else {
+        u32 r = 0;
 #pragma unroll
-    for (int k = 0; k < NP; ++k)
-        if ((q >> 6) == static_cast<u32>(k)) r = read_lane(v[k], q & 63u);
-    return r;
+        for (int k = 0; k < NP; ++k)
+            if ((q >> 6) == static_cast<u32>(k)) r = read_lane(v[k], q & 63u);
+        return r;
+    }
 }
 
 struct ParseState {
@@ -263,11 +276,28 @@ struct ParseState {
     bool pend, done;
 };
 
+// SNP_W_PROF=1: event counters (slots 0-7) ; =2: plus phase timers (slots 8-15, s_memtime with a drain at every mark)
 #if SNP_W_PROF
 __device__ unsigned long long g_wprof[16];
-#define WPROF_ADD(k, v) do { if (lane == 0) atomicAdd(&g_wprof[k], static_cast<unsigned long long>(v)); } while (0)
+#define WPROF_ADD(k, v) do { wacc[k] += static_cast<unsigned long long>(v); } while (0)
+#define WPROF_DECL unsigned long long wacc[16] = {0}; u64 wt_ = __builtin_readcyclecounter(); (void)wt_;
+#define WPROF_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 16; ++k_) if (wacc[k_]) atomicAdd(&g_wprof[k_], wacc[k_]); } while (0)
+#if SNP_W_PROF >= 2
+#define WPROF_T(k)                                                                \
+    do {                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
+        const u64 now_ = __builtin_readcyclecounter();                            \
+        wacc[k] += now_ - wt_;                                                    \
+        wt_ = now_;                                                               \
+    } while (0)
+#else
+#define WPROF_T(k)
+#endif
 #else
 #define WPROF_ADD(k, v)
+#define WPROF_DECL
+#define WPROF_FLUSH
+#define WPROF_T(k)
 #endif
 
 template <int VARIANT, int NP>
@@ -315,6 +345,9 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
 
         ParseState st{1u, 1u, 0u, false, false};
         u32 head = 0, cnt = 0;                                          // token ring
+        snp_u128_unaligned X[NP][kPieces];                              // the window's input bytes: kCap per position
+        u32 xn_base = kNone;                                            // window start X was prefetched for
+        WPROF_DECL
 
         // ---- emission of `nb` queued tokens, one per lane ------------------------------------------------------
         auto emit_batch = [&](u32 nb) {
@@ -375,109 +408,185 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
             st.S = bcast_first(st.S); st.pos = bcast_first(st.pos); st.kb = bcast_first(st.kb);
             st.pend = bcast_first(st.pend ? 1u : 0u) != 0;
             op = bcast_first(op); eprev = bcast_first(eprev); head = bcast_first(head); cnt = bcast_first(cnt);
+            xn_base = bcast_first(xn_base);
             const u32 w = st.pos - (st.pend ? 1u : 0u);
             const bool zone1 = (st.pos + 1 == st.S) || (st.pos - st.S <= 32);
             u32 cut0 = 0;
-            if (w + 17 <= n) { cut0 = n - 16 - w; if (cut0 > W) cut0 = W; }   // positions p with p + 17 <= n
+            if (w + kCap + 1 <= n) { cut0 = n - kCap - w; if (cut0 > W) cut0 = W; }   // positions p with p + kCap + 1 <= n
+            WPROF_T(15);
             if (zone1 && cut0 >= 16) {
                 // ================================ dense round ================================================
                 WPROF_ADD(0, 1);
-                snp_u128_unaligned X[NP];
                 u32 pp[NP], h[NP], c[NP], m[NP];
-                bool valid[NP], hit[NP], unres[NP];
+                bool valid[NP];
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     const u32 q = 64u * k + lane;
                     pp[k] = w + q;
                     valid[k] = q < cut0;
-                    if (valid[k]) X[k] = *reinterpret_cast<const snp_u128_unaligned*>(src + pp[k]);
-                    else X[k].v[0] = X[k].v[1] = X[k].v[2] = X[k].v[3] = 0;
                 }
+                if (xn_base != w) {                                     // not prefetched by the previous round
 #pragma unroll
-                for (int k = 0; k < NP; ++k) h[k] = bucket_of<VARIANT>(X[k].v[0], mask, hmask, lut);
+                    for (int k = 0; k < NP; ++k)
+#pragma unroll
+                        for (int j = 0; j < kPieces; ++j) {
+                            if (valid[k]) X[k][j] = *reinterpret_cast<const snp_u128_unaligned*>(src + pp[k] + 16 * j);
+                            else X[k][j].v[0] = X[k][j].v[1] = X[k][j].v[2] = X[k][j].v[3] = 0;
+                        }
+                }
+                WPROF_T(8);                                             // window load
+#pragma unroll
+                for (int k = 0; k < NP; ++k) h[k] = bucket_of<VARIANT>(X[k][0].v[0], mask, hmask, lut);
                 lds_fence();
 #pragma unroll
                 for (int k = 0; k < NP; ++k) c[k] = table[h[k]];
-#pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    m[k] = 0;
-                    if (valid[k]) {
-                        const snp_u128_unaligned E = *reinterpret_cast<const snp_u128_unaligned*>(src + c[k]);
-                        m[k] = common16(X[k], E);
-                    }
-                    hit[k] = valid[k] && m[k] >= 4;
-                    unres[k] = hit[k] && m[k] == 16;
-                }
-                // per-lane extension up to kCap bytes
-                for (u32 k16 = 16; k16 < kCap; k16 += 16) {
-                    bool any = false;
-                    bool go[NP];
-#pragma unroll
-                    for (int k = 0; k < NP; ++k) { go[k] = unres[k] && pp[k] + k16 + 16 <= n; any = any || go[k]; }
-                    if (!ballot64(any)) break;
+                WPROF_T(9);                                             // hash + table gather
+                u64 HITM[NP], UNRES[NP];
+                {
+                    snp_u128_unaligned E[NP][kPieces];
 #pragma unroll
                     for (int k = 0; k < NP; ++k)
-                        if (go[k]) {
-                            const snp_u128_unaligned A = *reinterpret_cast<const snp_u128_unaligned*>(src + pp[k] + k16);
-                            const snp_u128_unaligned E = *reinterpret_cast<const snp_u128_unaligned*>(src + c[k] + k16);
-                            const u32 mm = common16(A, E);
-                            m[k] += mm;
-                            unres[k] = mm == 16;
-                        }
-                }
-                WMask<NP> HITM, UNRES;
 #pragma unroll
-                for (int k = 0; k < NP; ++k) { HITM.w[k] = ballot64(hit[k]); UNRES.w[k] = ballot64(unres[k]); }
+                        for (int j = 0; j < kPieces; ++j)
+                            if (valid[k]) E[k][j] = *reinterpret_cast<const snp_u128_unaligned*>(src + c[k] + 16 * j);
+                            else E[k][j].v[0] = E[k][j].v[1] = E[k][j].v[2] = E[k][j].v[3] = ~0u;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        u32 mm = common16(X[k][0], E[k][0]);
+#pragma unroll
+                        for (int j = 1; j < kPieces; ++j)
+                            if (mm == 16u * j) mm += common16(X[k][j], E[k][j]);
+                        m[k] = mm;
+                        HITM[k] = ballot64(valid[k] && mm >= 4);
+                        UNRES[k] = ballot64(valid[k] && mm == kCap);
+                    }
+                }
+                WPROF_T(10);                                            // candidate gather + compare
 
-                // ---- scalar walk over [o, cut): visited probes V, ip-1 inserts INS, end state ---------------------
-                WMask<NP> V, INS;
+                // ---- scalar walk over [0, cut): which positions does the serial parse write (PUB), which of them are
+                //      copies (TOKM), where does it stand afterwards (e) -----------------------------------------------
+                u64 PUB[NP], TOKM[NP];
                 ParseState e;
                 auto walk = [&](u32 cut) {
-                    V.clear();
-                    INS.clear();
+                    u64 SK[NP];                                         // interiors of the copies: positions never visited
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) { SK[k] = 0; TOKM[k] = 0; }
                     e = st;
-                    u32 o = st.pos - w;
-                    if (st.pend) { INS.w[0] |= 1ull; e.pend = false; }
+                    e.pend = false;
+                    u32 o = st.pos - w;                                 // 0, or 1 behind the pending insert
+                    u32 srel = st.S - w;                                // scan start relative to the window (may wrap below 0: only srel + 32 is used)
+                    u32 end;
                     for (;;) {
-                        if (o >= cut) { e.pos = w + o; e.kb = e.pos >= e.S ? e.pos - e.S : 0u; return; }
-                        const u32 zone_end = e.S + 32 - w;             // last stride-1 position of this scan
-                        const u32 lim = zone_end < cut - 1 ? zone_end : cut - 1;
-                        const u32 t = HITM.first_in(o, lim);
-                        if (t == kNone) {
-                            V.set_range(o, lim);
-                            if (lim == zone_end) { e.pos = e.S + 34; e.kb = 33; }        // probe 33 is two bytes further (:319-320)
-                            else { e.pos = w + cut; e.kb = e.pos - e.S; }
-                            return;
+                        if constexpr (NP == 1 && SNP_W_ASMWALK) {
+                            // The common tokens -- resolved length < 60, copy ends inside the window -- in a hand-written scalar loop
+                            // (a lone wavefront issues one instruction every ~6 cycles: the walk is priced per instruction).
+                            // Anything else (no further hit, unresolved or long match, copy crossing the cut) falls out to the
+                            // generic code below, which handles one event and comes back.
+                            u64 x_;
+                            u32 t_, z_, ml_, ip_, a_, b_;
+                            const u32 cut_u = bcast_first(cut), cm1 = cut_u - 1;
+                            const u64 hit_u = bcast_first64(HITM[0]), unres_u = bcast_first64(UNRES[0]);
+                            o = bcast_first(o); srel = bcast_first(srel);
+                            TOKM[0] = bcast_first64(TOKM[0]); SK[0] = bcast_first64(SK[0]);
+                            asm volatile(
+                                "1:\n\t"
+                                "s_lshr_b64 %[x], %[hit], %[o]\n\t"
+                                "s_cmp_eq_u64 %[x], 0\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                "s_ff1_i32_b64 %[t], %[x]\n\t"
+                                "s_add_u32 %[t], %[t], %[o]\n\t"
+                                "s_add_u32 %[z], %[srel], 32\n\t"
+                                "s_min_u32 %[z], %[z], %[cm1]\n\t"
+                                "s_cmp_gt_u32 %[t], %[z]\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                "s_bitcmp1_b64 %[unres], %[t]\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                "v_readlane_b32 %[ml], %[vm], %[t]\n\t"
+                                "s_nop 0\n\t"
+                                "s_cmp_gt_u32 %[ml], 59\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                "s_add_u32 %[ip], %[t], %[ml]\n\t"
+                                "s_cmp_ge_u32 %[ip], %[cut]\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                "s_bitset1_b64 %[tok], %[t]\n\t"
+                                "s_sub_u32 %[a], %[ml], 2\n\t"
+                                "s_add_u32 %[b], %[t], 1\n\t"
+                                "s_bfm_b64 %[x], %[a], %[b]\n\t"
+                                "s_or_b64 %[sk], %[sk], %[x]\n\t"
+                                "s_add_u32 %[srel], %[ip], 1\n\t"
+                                "s_mov_b32 %[o], %[ip]\n\t"
+                                "s_branch 1b\n\t"
+                                "2:\n\t"
+                                : [o] "+s"(o), [srel] "+s"(srel), [tok] "+s"(TOKM[0]), [sk] "+s"(SK[0]), [x] "=&s"(x_), [t] "=&s"(t_),
+                                  [z] "=&s"(z_), [ml] "=&s"(ml_), [ip] "=&s"(ip_), [a] "=&s"(a_), [b] "=&s"(b_)
+                                : [hit] "s"(hit_u), [unres] "s"(unres_u), [vm] "v"(m[0]), [cut] "s"(cut_u), [cm1] "s"(cm1)
+                                : "scc");
+                            e.S = w + srel;
                         }
-                        V.set_range(o, t);
+                        const u32 t = mask_first_from<NP>(HITM, o);
+                        const u32 zend = srel + 32;
+                        const u32 lim = zend < cut - 1 ? zend : cut - 1;
+                        if (t > lim) {                                  // no hit before the zone / window ends
+                            end = lim;
+                            if (lim == zend) { e.pos = w + srel + 34; e.kb = 33; }   // probe 33 lies two bytes further (:319-320)
+                            else { e.pos = w + cut; e.kb = e.pos >= e.S ? e.pos - e.S : 0u; }
+                            break;
+                        }
+                        mask_set_bit<NP>(TOKM, t);
                         u32 ml = read_half<NP>(m, t);
-                        if (UNRES.test(t)) {
+                        if (mask_test<NP>(UNRES, t)) {
                             WPROF_ADD(3, 1);
+                            WPROF_T(12);
                             ml = wave_match_extend(src, n, w + t, read_half<NP>(c, t), ml, lane);
 #pragma unroll
                             for (int k = 0; k < NP; ++k) {
                                 if (64u * k + lane == t) m[k] = ml;
-                                if ((t >> 6) == static_cast<u32>(k)) UNRES.w[k] &= ~(1ull << (t & 63u));
+                                if ((t >> 6) == static_cast<u32>(k)) UNRES[k] &= ~(1ull << (t & 63u));
                             }
+                            WPROF_T(11);                                // whole-wave match extension
                         }
-                        const u32 ip = w + t + ml;
-                        if (ip >= limit) { e.done = true; e.pos = ip; return; }          // :381-384
-                        e.S = ip + 1;
-                        e.pos = ip;
-                        e.kb = 0;
-                        if (t + ml - 1 < cut) INS.set_bit(t + ml - 1);
-                        else { e.pend = true; return; }
-                        o = t + ml;
+                        const u32 ip = t + ml;
+                        if (w + ip >= limit) { e.done = true; e.pos = w + ip; end = t; break; }   // :381-384 (no ip-1 insert)
+                        mask_set_range<NP>(SK, t + 1, ip - 2);          // ip-1 is inserted (:393-394), ip is probed (:395-398)
+                        e.S = w + ip + 1;
+                        srel = ip + 1;
+                        if (ip >= cut) { e.pos = w + ip; e.kb = 0; e.pend = ip - 1 >= cut; end = cut - 1; break; }
+                        o = ip;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        u64 r = 0;
+                        if (end >= 64u * k) r = end - 64u * k >= 63 ? ~0ull : (2ull << (end - 64u * k)) - 1ull;
+                        PUB[k] = r & ~SK[k];
                     }
                 };
                 walk(cut0);
+                WPROF_T(12);                                            // walk
+                // prefetch the next window while this one is published and queued (a cut below moves the window: reload then)
+                xn_base = kNone;
+                if (!e.done) {
+                    const u32 wn = e.pos - (e.pend ? 1u : 0u);
+                    const bool z1 = (e.pos + 1 == e.S) || (e.pos - e.S <= 32);
+                    u32 cn = 0;
+                    if (wn + kCap + 1 <= n) { cn = n - kCap - wn; if (cn > W) cn = W; }
+                    if (z1 && cn >= 16) {
+                        xn_base = wn;
+#pragma unroll
+                        for (int k = 0; k < NP; ++k)
+#pragma unroll
+                            for (int j = 0; j < kPieces; ++j) {
+                                if (64u * k + lane < cn) X[k][j] = *reinterpret_cast<const snp_u128_unaligned*>(src + wn + 64u * k + lane + 16 * j);
+                                else X[k][j].v[0] = X[k][j].v[1] = X[k][j].v[2] = X[k][j].v[3] = 0;
+                            }
+                    }
+                }
                 // ---- publish, read back: pairwise distinct buckets? ----------------------------------------------------
                 bool pub[NP];
                 u32 rb[NP];
                 bool bad = false;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    pub[k] = ((V.w[k] | INS.w[k]) >> lane) & 1ull;
+                    pub[k] = (PUB[k] >> lane) & 1ull;
                     if (pub[k]) table[h[k]] = static_cast<u16>(pp[k]);
                 }
                 lds_fence();
@@ -512,9 +621,10 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                         if (pub[k]) table[h[k]] = static_cast<u16>(c[k]);
                     lds_fence();
                     walk(q2);
+                    xn_base = kNone;                                    // the prefetched window started somewhere else
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
-                        pub[k] = ((V.w[k] | INS.w[k]) >> lane) & 1ull;
+                        pub[k] = (PUB[k] >> lane) & 1ull;
                         if (pub[k]) table[h[k]] = static_cast<u16>(pp[k]);
                     }
                     lds_fence();
@@ -523,7 +633,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                 u32 pushed = 0;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    const u64 tm = V.w[k] & HITM.w[k];
+                    const u64 tm = TOKM[k];
                     if ((tm >> lane) & 1ull) {
                         const u32 idx = cnt + pushed + static_cast<u32>(__builtin_popcountll(tm & lanes_below(lane)));
                         ring[(head + idx) & 127u] = static_cast<u64>(pp[k]) | (static_cast<u64>(m[k]) << 16) | (static_cast<u64>(pp[k] - c[k]) << 32);
@@ -534,9 +644,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                 cnt += pushed;
                 st = e;
                 lds_fence();
+                WPROF_T(13);                                            // publish / cut / queue
             } else {
                 // ================================ sparse round ===============================================
                 WPROF_ADD(4, 1);
+                xn_base = kNone;
                 const u32 sh = st.pend ? 1u : 0u;
                 const bool postcopy = st.pos + 1 == st.S;
                 const bool is_ins = st.pend && lane == 0;
@@ -621,9 +733,10 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                 }
                 lds_fence();
             }
-            if (cnt >= 64) emit_batch(64);
+            if (cnt >= 64) { WPROF_T(15); emit_batch(64); WPROF_T(14); }
         }
         if (cnt) emit_batch(cnt);
+        WPROF_FLUSH;
     }
     if (eprev < n) op = wave_emit_literal(dst, op, src, eprev, n - eprev, lane);   // emit_remainder  :406-411
 

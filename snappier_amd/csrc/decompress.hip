@@ -203,6 +203,10 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
     u8* dst = out + out_off[b] - skip;                                  // output offsets below count from `skip` bytes early
     const u32 cap = bcast_first(out_cap[b]);
 
+    if (n > 0x7fffffffu - 1024u) {                       // the reference's spans are int-length; keeps ip + k arithmetic below 2^32
+        if (lane == 0) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; }
+        return;
+    }
     if (!FRAG && chunk_type && chunk_type[b] == 1) {     // framing: uncompressed chunk body  SnappyStreamDecompressor.cs:137-163
         const bool fits = n <= cap;
         if (fits) wave_copy(dst, src, n, lane);

@@ -169,6 +169,8 @@ __global__ __launch_bounds__(SNP_WAVE) void k_frame_scan(const u8* __restrict__ 
                     }
                     if (bad || !done || result > 0x7fffffffu) { tail = SNP_ERR_BAD_LENGTH; break; }
                     dec = result;
+                    // no tag expands more than 3 bytes -> 64: such a chunk can only end "Incomplete Snappy block." (capi.hip scan_chunks)
+                    if (static_cast<u64>(dec) > (static_cast<u64>(size - 4 - (shift / 7)) / 3 + 1) * 64) { tail = SNP_ERR_INCOMPLETE; break; }
                 }
                 if (nc == max_chunks) { tail = SNP_ERR_OUTPUT_TOO_SMALL; break; }   // chunk table full
                 type[nc] = static_cast<u8>(t);

@@ -78,3 +78,23 @@ def test_status_strings_match_reference_messages():
     assert S.status_string(N.ERR_BAD_LENGTH) == "Invalid stream length"               # VarIntEncoding.Read.cs:20
     assert S.status_string(N.ERR_CRC_MISMATCH) == "Chunk CRC mismatch."               # SnappyStreamDecompressor.cs:130
     assert S.status_string(N.ERR_OUTPUT_TOO_SMALL) == "Output buffer is too small."   # ThrowHelper.cs:18-19
+
+
+def test_frame_chunk_cannot_declare_more_than_it_can_produce():
+    """A ~20-byte stream whose chunk declares 2 GiB must not size any allocation: no tag expands more than 3 bytes -> 64,
+    so the chunk can only end "Incomplete Snappy block." (host header walk, no device needed; the device walk applies the
+    same bound -- tests/test_gpu_parity.py)."""
+    from snappier_amd import _native as N
+    L = C.CDLL(N.LIB_PATH)
+    L.snp_frame_decoded_length.restype = C.c_int
+    L.snp_frame_decoded_length.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    head = bytes([0xFF, 0x06, 0x00, 0x00, 0x73, 0x4E, 0x61, 0x50, 0x70, 0x59])
+    body = bytes([0xFF, 0xFF, 0xFF, 0xFF, 0x07]) + bytes([0x00, 0x41])            # varint 2^31-1, then a 1-byte literal
+    chunk = bytes([0x00]) + (4 + len(body)).to_bytes(3, "little") + bytes(4) + body
+    total = C.c_uint64(123)
+    assert L.snp_frame_decoded_length(head + chunk, len(head + chunk), C.byref(total)) == 4      # SNP_ERR_INCOMPLETE
+    assert total.value == 0
+    # a chunk at the bound is still accepted by the walk (it is the decoder's business from there on)
+    body = bytes([64]) + bytes([0xFE, 0x01, 0x00])                                 # declares 64, one copy-2 tag
+    chunk = bytes([0x00]) + (4 + len(body)).to_bytes(3, "little") + bytes(4) + body
+    assert L.snp_frame_decoded_length(head + chunk, len(head + chunk), C.byref(total)) == 0 and total.value == 64

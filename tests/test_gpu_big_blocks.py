@@ -194,6 +194,35 @@ def test_work_follows_torch_streams():
     assert same and int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0
 
 
+def test_one_context_alternating_between_two_streams_keeps_its_scratch_ordered(monkeypatch):
+    """The lane compressor's hash tables live in context-owned HBM scratch.  A context that is rebound from one torch
+    stream to another (double buffering) must not let the second launch's memset + kernel run on the tables while the
+    first is still using them: snp_ctx_set_stream orders the new stream behind the old one.  Both results must be the
+    oracle's bytes."""
+    from snappier_amd import batch as SB, datagen as SD
+    monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", "lanes")
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    html = read_testdata("html")
+    nb = 4096
+    raws = [SD.html_like_blocks(html, 100 + 7 * k, nb, "cuda") for k in range(4)]
+    in_off, in_len = cd.uniform_layout(nb)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    results = []
+    for k, raw in enumerate(raws):                                     # no sync between the launches
+        with torch.cuda.stream(streams[k & 1]):
+            results.append(cd.compress(raw, in_off, in_len))
+    torch.cuda.synchronize()
+    for k, (out, out_off, out_len, status) in enumerate(results):
+        assert int((status != 0).sum()) == 0
+        lens = out_len.cpu().numpy()
+        for b in range(0, nb, 257):
+            blk = raws[k][b * 65536:(b + 1) * 65536].cpu().numpy().tobytes()
+            got = out[b * cd.comp_stride: b * cd.comp_stride + int(lens[b])].cpu().numpy().tobytes()
+            assert got == O.compress(blk, O.HASH_CRC32C), (k, b)
+    assert torch.cuda.current_device() == 0                            # entry points leave the current device alone
+
+
 def test_fuzz_corrupted_big_blocks_match_the_oracle(ctx):
     """Random corruptions of large blocks through the host API: whatever path runs (fragments, fallback, single
     wavefront), status and bytes are the oracle's."""

@@ -84,11 +84,11 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("layout", ["win", "win1", "wave", "lanes"])
+@pytest.mark.parametrize("layout", ["win", "win2", "wave", "lanes"])
 @pytest.mark.parametrize("variant", [O.HASH_CRC32C, O.HASH_MUL])
 def test_fuzz_compress_bytes_equal_oracle(layout, variant, monkeypatch):
     monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout)
-    monkeypatch.setenv("SNAPPIER_HIP_WIN_NP", "1" if layout == "win1" else "2")
+    monkeypatch.setenv("SNAPPIER_HIP_WIN_NP", "2" if layout == "win2" else "1")
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
     cd = SB.BlockCodec(0, variant)
     for r in range(ROUNDS):

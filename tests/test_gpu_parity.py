@@ -327,13 +327,13 @@ def test_decompress_batch_per_block_status(codec):
     assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
 
 
-@pytest.mark.parametrize("layout", ["win", "win-np1", "wave", "wave-staged", "wave-unstaged", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31"])
+@pytest.mark.parametrize("layout", ["win", "win-np2", "wave", "wave-staged", "wave-unstaged", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31"])
 def test_compress_layouts_are_bit_identical(layout, monkeypatch):
     """Both compressor layouts (one fragment per wavefront with the table in LDS; one fragment per lane with the table
     in an HBM workspace) must give the oracle's bytes on every kind of input, ragged lengths included."""
     monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout.split("-")[0])
-    if layout == "win-np1":             # window compressor with one position per lane (default two)
-        monkeypatch.setenv("SNAPPIER_HIP_WIN_NP", "1")
+    if layout == "win-np2":             # window compressor with two positions per lane (default one)
+        monkeypatch.setenv("SNAPPIER_HIP_WIN_NP", "2")
     if layout.endswith("-exact"):       # short literals stored with exact-length stores instead of one 16-byte store
         monkeypatch.setenv("SNAPPIER_HIP_EXACT_LITERALS", "1")
     if "-opts" in layout:               # lane kernel with another set of output-store options (default 23; 7 = no LDS staging)

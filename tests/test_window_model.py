@@ -14,7 +14,7 @@ CORPUS = ["html", "alice29.txt", "asyoulik.txt", "kppkn.gtb", "fireworks.jpeg", 
           "lcet10.txt", "plrabn12.txt", "urls.10K"]
 
 
-def check(data: bytes, variant: int, np_: int = 2, cap: int = 48, stats=None):
+def check(data: bytes, variant: int, np_: int = 2, cap: int = 32, stats=None):
     got = WM.compress(data, variant, np_, cap, stats)
     ref = O.compress(data, variant)
     assert got == ref, (len(data), variant, np_, cap, len(got), len(ref))
@@ -26,7 +26,7 @@ def test_corpus_whole_files(name, variant):
     data = read_testdata(name)[:4 * 65536 + 1234]
     for np_ in (1, 2, 4):
         st = WM.Stats()
-        check(data, variant, np_, 48, st)
+        check(data, variant, np_, 32, st)
         assert st.dense_rounds + st.sparse_rounds > 0
     check(data[:65536], variant, 2, 16)
 

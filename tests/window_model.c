@@ -123,7 +123,7 @@ static int walk(const uint8_t* in, uint32_t n, uint32_t limit, uint32_t w, uint3
         if (t > lim) {
             for (uint32_t q = o; q <= lim; ++q) visited[q] = 1;
             if (lim == zone_end) { st->pos = st->S + 34; st->kb = 33; }   /* probe 33 lies two bytes further (:319-320) */
-            else { st->pos = w + cut; st->kb = st->pos - st->S; }
+            else { st->pos = w + cut; st->kb = st->pos >= st->S ? st->pos - st->S : 0; }
             return nt;
         }
         for (uint32_t q = o; q <= t; ++q) visited[q] = 1;
@@ -162,8 +162,8 @@ size_t wm_compress_fragment(const uint8_t* in, uint32_t n, uint8_t* out, int var
         while (!st.done) {
             const uint32_t w = st.pend ? st.pos - 1 : st.pos;
             const int zone1 = (st.pos + 1 == st.S) || (st.pos - st.S <= 32);
-            uint32_t cut0 = 0;                                       /* window positions p with p + 17 <= n */
-            if (w + 17 <= n) { cut0 = n - 16 - w; if (cut0 > W) cut0 = W; }
+            uint32_t cut0 = 0;                                       /* window positions p with p + cap + 1 <= n: cap-byte loads stay inside */
+            if (w + (uint32_t)cap + 1 <= n) { cut0 = n - (uint32_t)cap - w; if (cut0 > W) cut0 = W; }
             int nt;
             pstate trial;
             if (zone1 && cut0 >= 16) {

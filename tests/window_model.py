@@ -29,7 +29,7 @@ def lib():
     return _lib
 
 
-def compress(data: bytes, variant: int, np_: int = 2, cap: int = 48, stats: Stats | None = None) -> bytes:
+def compress(data: bytes, variant: int, np_: int = 2, cap: int = 32, stats: Stats | None = None) -> bytes:
     out = C.create_string_buffer(len(data) + len(data) // 6 + 64 + 40 * (len(data) // 65536 + 1))
     n = lib().wm_compress(data, len(data), out, variant, np_, cap, C.byref(stats) if stats is not None else None)
     return out.raw[:n]
