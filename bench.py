@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on BASELINE.json's config, on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
+                                                             torch.distributed.run, one process per GPU, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --config 5 ...                          BASELINE.json configs[4]: mixed-corpus blocks, block-sharded
 
 Workload (config.workload): BASELINE.json configs[1] -- 10 GiB of 64 KiB html-like blocks per GPU (163 840 blocks:
 the html fixture tiled at a per-block offset + ~1 % byte mutations, seed 0x5EED0001; weak scaling, rank r owns
@@ -78,16 +80,28 @@ def main():
     ap.add_argument("--hash", choices=["crc32c", "mul"], default="crc32c")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16384)
+    ap.add_argument("--config", type=int, choices=[2, 5], default=2,
+                    help="2 = BASELINE configs[1] (html-like blocks, the headline); 5 = configs[4] (mixed-corpus blocks, "
+                         "block-sharded, plus the compaction and payload-gather lines)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one process per GPU over RCCL, rendezvous on 127.0.0.1
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: the codec has no CPU fallback")
+        sys.exit(f"bench.py needs an MI355X: the codec has no CPU fallback (rank {rank} of {world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or "RANK" in os.environ             # under torch.distributed.run: always take the RCCL path
@@ -110,7 +124,15 @@ def main():
     with open(os.path.join(ROOT, "tests", "golden", "testdata", "html"), "rb") as f:
         html = f.read()
     cd = SB.BlockCodec(local_rank, variant)
-    raw = SD.html_like_blocks(html, rank * nb, nb, dev)
+    if args.config == 5:        # mixed corpus: block b takes corpus file b mod 11, rank r owns [r*nb, (r+1)*nb)
+        td = os.path.join(ROOT, "tests", "golden", "testdata")
+        names = ["alice29.txt", "asyoulik.txt", "fireworks.jpeg", "geo.protodata", "html", "html_x_4", "kppkn.gtb", "lcet10.txt",
+                 "paper-100k.pdf", "plrabn12.txt", "urls.10K"]
+        def corpus_file(f):     # html_x_4 = html repeated four times (SnappyTests.cs:8-19 corpus order)
+            return html * 4 if f == "html_x_4" else open(os.path.join(td, f), "rb").read()
+        raw = SD.corpus_blocks([corpus_file(f) for f in names], rank * nb, nb, SD.MIXED_SEED, dev)
+    else:
+        raw = SD.html_like_blocks(html, rank * nb, nb, dev)
     in_off, in_len = cd.uniform_layout(nb)
     comp = torch.empty(nb * cd.comp_stride, dtype=torch.uint8, device=dev)
     comp_off = torch.arange(nb, dtype=torch.int64, device=dev) * cd.comp_stride
@@ -144,16 +166,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out_len, status, dlen, dst = step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn, reps):
+        """max over ranks of the wall time of `reps` calls of fn, bracketed by barrier + synchronize on both sides"""
+        barrier()
+        t0 = time.perf_counter()
+        r = None
+        for _ in range(reps):
+            r = fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, r
+
+    elapsed, (out_len, status, dlen, dst) = timed(lambda: step(True), args.steps)
+
+    # ---- config 5: the lines around the codec (never part of `value`) -------------------------------------------------
+    extra = {}
+    if args.config == 5:
+        def codec_only():
+            _o, _oo, ol, stt = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
+            cd.decompress(comp, comp_off, ol, back, in_off, in_len)
+            return ol, stt
+        def compact_and_gather():       # what a real 8-GPU job ends with: compact this rank's blocks, directory, payload to rank 0
+            ol, stt = out_len, status
+            stream, _dst = cd.compact(comp, comp_off, ol)
+            all_len, _all_st, _offs = sharding.gather_directory(ol, stt, nb * world)
+            got = sharding.gather_payload(stream, all_len, nb * world, dst=0)
+            return got
+        reps = max(1, min(args.steps, 3))
+        t_codec, _ = timed(codec_only, reps)
+        t_gather, gathered = timed(compact_and_gather, reps)
+        extra = {"codec_only_GBps": round(float(nb) * BLOCK * world / (t_codec / reps) / 1e9, 2),
+                 "codec_plus_directory_GBps": round(float(nb) * BLOCK * world / (elapsed / args.steps) / 1e9, 2),
+                 "compact_plus_payload_gather_ms": round(t_gather / reps * 1e3, 2),
+                 "payload_gather_GBps_compressed": (round(float(gathered.numel()) / (t_gather / reps) / 1e9, 2)
+                                                    if gathered is not None and t_gather > 0 else None)}
 
     # ---- verification (outside the timed region): every status OK, decode(encode(x)) == x -----------------------
     ok = int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and bool((dlen == BLOCK).all()) and torch.equal(back, raw)
@@ -171,22 +221,32 @@ def main():
         # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per
         # pass, same workload): per-block figures x blocks of this run.  See profiles/r01k_hbm_traffic.json for the caveat
         # on the gfx950 FETCH_SIZE calibration.
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01k_hbm_traffic.json")) as f:
-                pmc = json.load(f)["kernels"]
-        except OSError:
-            pmc = {}
+        pmc, pmc_file = {}, None
+        for cand in ("r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", cand)) as f:
+                    pmc, pmc_file = json.load(f)["kernels"], cand
+                break
+            except OSError:
+                continue
         def roof(ms, kernel):
             a = alg / (ms * 1e-3) / 1e9
             t = pmc.get(kernel)
-            traffic = int((t["fetch_bytes_per_block"] + t["write_bytes_per_block"]) * nb) if t and args.hash == "crc32c" else None
+            traffic = int((t["fetch_bytes_per_block"] + t["write_bytes_per_block"]) * nb) if t and args.hash == "crc32c" and args.config == 2 else None
             return {"bound": "hbm", "kernel": kernel, "achieved": round(a, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBPS, 5), "traffic": traffic, "avg_launch_ms": round(ms, 4),
+                    "frac": round(a / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "traffic_source": (f"replayed: per-block FETCH_SIZE + WRITE_SIZE of profiles/{pmc_file} (separate rocprofv3 --pmc "
+                                       "passes over this workload) x blocks of this run; not measured in this process") if traffic else None,
+                    "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": int(alg),
                     "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}
-        r_c = roof(ms_c, "k_compress_lanes" if nb >= 8192 else "k_compress")
+        lanes = nb >= 16384
+        r_c = roof(ms_c, "k_compress_lanes" if lanes else "k_compress_win")
         r_d = roof(ms_d, "k_decompress")
-        if nb >= 8192:
+        if lanes:
+            r_c["table_workspace_probe"] = {"chosen_ms": S.lib().snp_ctx_counter(cd.ctx.handle, 2) / 1e3,
+                                            "candidates": S.lib().snp_ctx_counter(cd.ctx.handle, 3)}
+        if lanes and args.config == 2:
             # What bounds the lane compressor is not U + C but the random 4-byte read-modify-writes of its hash tables
             # (DESIGN.md 4.3).  Rates: scripts/microbench_random_table.hip on this GPU model (profiles/
             # r01d_microbench_random_table.jsonl: 20.26 G read+write probes/s, 23.57 G write-only inserts/s); counts: the
@@ -202,10 +262,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 10 GiB of 64 KiB html-like blocks per GPU, "
+            "config": {"workload": ("configs[1]: 10 GiB of 64 KiB html-like blocks per GPU, " if args.config == 2 else
+                                    "configs[4]: 10 GiB of mixed-corpus 64 KiB blocks per GPU (80 GiB at 8 GPUs), ") +
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
-                       "layout": "decompress: one block per wavefront; compress: one fragment per lane (>= 8192 fragments), else one per wavefront",
+                       "layout": "decompress: one block per wavefront; compress: one fragment per lane with HBM tables (>= 16384 fragments), else one per wavefront with the table in LDS",
+                       "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,
             "decompress_GBps": round(u_bytes * world / (ms_d * 1e-3) / 1e9, 2) if world == 1 else None,
@@ -213,6 +275,8 @@ def main():
             "roofline_compress": r_c, "roofline_decompress": r_d,
             "verified": "decode(encode(x)) == x for every block, all status OK",
         }
+        if extra:
+            line["config5_lines"] = extra
         if world == 1 and not args.no_cpu_baseline:
             ns = min(args.cpu_sample_blocks, nb)
             line["cpu_baseline"] = cpu_baseline(raw[: ns * BLOCK].cpu().numpy(), variant)

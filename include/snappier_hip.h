@@ -83,7 +83,9 @@ const char* snp_ctx_last_error(const snp_ctx* ctx);
 snp_status snp_ctx_synchronize(snp_ctx* ctx);
 /* Introspection for tests and tuning: how often this context took a code path since it was created.
  * which: 0 = large single blocks decoded one wavefront per 64 KiB fragment (snp_try_decompress, tag index),
- *        1 = large single blocks that fell back to the single-wavefront decoder (foreign / malformed streams). */
+ *        1 = large single blocks that fell back to the single-wavefront decoder (foreign / malformed streams),
+ *        2 = microseconds the chosen hash-table workspace took in the placement probe (0: no probe ran),
+ *        3 = workspace candidates that were probed. */
 uint64_t snp_ctx_counter(const snp_ctx* ctx, int which);
 const char* snp_status_string(int status);
 const char* snp_version(void);
@@ -130,7 +132,9 @@ snp_status snp_frame_decode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* 
  * block b reads in[in_off[b] .. +in_len[b]) and writes  varint(in_len[b]) || CompressFragment  at
  * out[out_off[b] ..), which must have room for snp_max_compressed_length(in_len[b]) bytes.
  * out_len[b] = bytes written, status[b] = SNP_OK | SNP_ERR_BAD_ARG (in_len[b] > 65536).
- * One wavefront per block; hash table in LDS.  All arrays are device memory. */
+ * Layout by batch size: below 16 384 fragments one fragment per wavefront with the u16 hash table in LDS
+ * (compress_win.hip), from there on one fragment per LANE with the tables in an HBM workspace the context owns
+ * (compress_lanes.hip); both emit the reference's bytes.  All arrays are device memory. */
 snp_status snp_compress_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
                               uint32_t nblocks, uint8_t* out, const uint64_t* out_off, uint32_t* out_len,
                               int32_t* status);
@@ -142,9 +146,17 @@ snp_status snp_decompress_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t*
                                 uint32_t nblocks, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
                                 uint32_t* out_len, int32_t* status);
 
-/* CRC-32C (optionally masked) of nblocks independent byte ranges; table-free, wave-parallel. */
+/* CRC-32C (optionally masked) of nblocks independent byte ranges; wave-parallel (each lane folds its dwords with a
+ * GF(2)-linear shift map applied sliced-by-8 from four 256-entry tables in LDS, crc32c.hip). */
 snp_status snp_crc32c_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
                             uint32_t nblocks, int masked, uint32_t* out_crc);
+
+/* Concatenate nblocks byte ranges: out[dst_off[b] .. +in_len[b]) = in[in_off[b] .. +in_len[b]).  This is the compaction
+ * step after snp_compress_batch (blocks sit at a fixed stride) -- what SnappyCompressor.TryCompress does by advancing
+ * its output span fragment after fragment (SnappyCompressor.cs:40-80) -- and what a rank does before the payload gather
+ * of a multi-GPU job.  dst_off = exclusive prefix sum of the lengths (device memory, computed by the caller). */
+snp_status snp_concat_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
+                            uint32_t nblocks, uint8_t* out, const uint64_t* dst_off);
 
 /* Device-resident framing (config 4): raw stream d_in[0..n) -> framed stream in d_out (capacity cap, device),
  * *d_written (device u64) = encoded size.  d_work must hold snp_frame_encode_workspace(n) bytes. */

@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
         "snp_compress_batch": (i32, [vp, vp, vp, vp, u32, vp, vp, vp, vp]),
         "snp_decompress_batch": (i32, [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp]),
         "snp_crc32c_batch": (i32, [vp, vp, vp, vp, u32, i32, vp]),
+        "snp_concat_batch": (i32, [vp, vp, vp, vp, u32, vp, vp]),
         "snp_frame_encode_workspace": (u64, [u64]),
         "snp_frame_encode_device": (i32, [vp, vp, u64, vp, u64, vp, vp]),
         "snp_frame_decode_chunks_device": (i32, [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp]),

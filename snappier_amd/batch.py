@@ -68,6 +68,19 @@ class BlockCodec:
         raise_for_status(st, self.ctx.handle)
         return out_len, status
 
+    def compact(self, data: torch.Tensor, in_off: torch.Tensor, in_len: torch.Tensor):
+        """Concatenate the blocks (snp_concat_batch): -> (stream tensor sized to the exact total, dst_off).  Needs the
+        total on the host (one sync) to size the result."""
+        self._bind()
+        nb = in_len.numel()
+        lens = in_len.to(torch.int64)
+        dst_off = torch.cumsum(lens, 0) - lens
+        total = int(lens.sum().item()) if nb else 0
+        out = torch.empty(total, dtype=torch.uint8, device=self.device)
+        st = N.lib().snp_concat_batch(self.ctx.handle, _p(data), _p(in_off), _p(in_len), nb, _p(out), _p(dst_off))
+        raise_for_status(st, self.ctx.handle)
+        return out, dst_off
+
     def crc32c(self, data: torch.Tensor, in_off: torch.Tensor, in_len: torch.Tensor, masked: bool = False):
         self._bind()
         nb = in_len.numel()

@@ -67,7 +67,7 @@ struct snp_ctx {
     int win_np = 1;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2; 2 measured slower)
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
     DevBuf in, out, meta, work, tables;
-    uint64_t counters[2] = {0, 0};   // snp_ctx_counter
+    uint64_t counters[4] = {0, 0, 0, 0};   // snp_ctx_counter
     std::string err;
 
     // One launch of the decompressor over nblocks blocks, picking the layout (see decompress_lanes.hip).
@@ -156,6 +156,8 @@ struct snp_ctx {
         for (int k = 0; k < got; ++k)
             if (k != best && cand[k]) (void)hipFree(cand[k]);
         if (best < 0) { err = "hipMalloc(hash tables): out of memory"; return false; }
+        counters[2] = tries > 1 ? static_cast<uint64_t>(best_ms * 1000.0f) : 0;
+        counters[3] = tries > 1 ? static_cast<uint64_t>(got) : 0;
         tables.p = cand[best];
         tables.cap = want;
         return true;
@@ -234,7 +236,7 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     return SNP_OK;
 }
 
-uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 2) ? c->counters[which] : 0; }
+uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 4) ? c->counters[which] : 0; }
 
 void snp_ctx_destroy(snp_ctx* c)
 {
@@ -362,6 +364,16 @@ snp_status snp_decompress_batch(snp_ctx* c, const uint8_t* in, const uint64_t* i
     if (!dg.ok) return SNP_ERR_DEVICE;
     return c->launch_decompress(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, nullptr) ? SNP_OK
                                                                                                               : SNP_ERR_DEVICE;
+}
+
+snp_status snp_concat_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t nblocks,
+                            uint8_t* out, const uint64_t* dst_off)
+{
+    if (!c || (nblocks && (!in || !in_off || !in_len || !out || !dst_off))) return SNP_ERR_BAD_ARG;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
+    if (nblocks == 0) return SNP_OK;
+    return c->check(snp_launch_gather(in, in_off, in_len, out, dst_off, nblocks, c->stream), "concat launch") ? SNP_OK : SNP_ERR_DEVICE;
 }
 
 snp_status snp_crc32c_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle as O
-from conftest import read_testdata
+from conftest import ROOT, read_testdata
 import datagen
 
 
@@ -78,3 +78,18 @@ def test_two_rank_directory_and_payload_gather():
     for b in range(nblocks):
         s = int(offsets[b])
         assert O.decompress(payload[s:s + int(all_len[b])].tobytes()) == x[b * 65536:(b + 1) * 65536].tobytes()
+
+
+def test_bench_spawns_one_process_per_gpu_by_itself():
+    """`python bench.py --gpus 2` (no launcher) must re-execute itself under torch.distributed.run with a 127.0.0.1
+    rendezvous: here, without a GPU, each of the two ranks then stops at the "needs an MI355X" check."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--blocks", "64"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    text = r.stdout + r.stderr
+    if "needs an MI355X" not in text:
+        pytest.skip("a GPU is present: the spawn path is exercised by the driver's own multi-GPU run")
+    assert r.returncode != 0
+    assert "rank 0 of 2" in text and "rank 1 of 2" in text, text[-2000:]
