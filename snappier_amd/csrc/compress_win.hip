@@ -746,7 +746,20 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
     }
 }
 
+// test hook: FindMatchLength by the wave, as the kernel uses it (tests/test_gpu_parity.py runs the reference's KATs through it)
+__global__ __launch_bounds__(SNP_WAVE) void k_debug_match_length(const u8* buf, u32 n, u32 p, u32 cand, u32 known, u32* out)
+{
+    const u32 r = wave_match_extend(buf, n, p, cand, known, lane_id());
+    if (lane_id() == 0) *out = r;
+}
+
 }  // namespace
+
+extern "C" int snp_debug_match_length(const u8* d_buf, u32 n, u32 p, u32 cand, u32 known, u32* d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_debug_match_length, dim3(1), dim3(SNP_WAVE), 0, stream, d_buf, n, p, cand, known, d_out);
+    return static_cast<int>(hipGetLastError());
+}
 
 #if SNP_W_PROF
 extern "C" int snp_debug_read_wprof(unsigned long long* out16, int reset)

@@ -138,6 +138,40 @@ def test_bad_long_length_and_small_buffers():                     # SnappyTests.
         Snappy.Compress(buf[:1024], buf[1023:])
 
 
+def test_compress_and_decompress_limited_output_buffer():        # SnappyTests.cs:41-63
+    """Output buffer smaller than GetMaxCompressedLength but larger than the actual compressed length
+    (SnappyCompressor.cs:56-74: compress to scratch, then copy), down to exactly the compressed length; one byte less fails."""
+    data = read_testdata("alice29.txt")[:65536]
+    ref = O.compress(data)
+    for cap in (Snappy.GetMaxCompressedLength(len(data)) - 5, len(ref) + 1, len(ref)):
+        buf = np.zeros(cap, dtype=np.uint8)
+        n = Snappy.Compress(data, buf)
+        assert n == len(ref) and buf[:n].tobytes() == ref
+        out = np.zeros(Snappy.GetUncompressedLength(buf[:n].tobytes()), dtype=np.uint8)
+        assert Snappy.Decompress(buf[:n].tobytes(), out) == len(data) and out.tobytes() == data
+    assert Snappy.TryCompress(data, np.zeros(len(ref) - 1, dtype=np.uint8)) == (False, 0)
+    with pytest.raises(S.InsufficientBufferException):
+        Snappy.Compress(data, np.zeros(len(ref) - 1, dtype=np.uint8))
+    big = read_testdata("alice29.txt")                                                  # multi-fragment, same rule
+    ref = O.compress(big)
+    buf = np.zeros(len(ref), dtype=np.uint8)
+    assert Snappy.Compress(big, buf) == len(ref) and buf.tobytes() == ref
+
+
+@pytest.mark.parametrize("expected,s1,s2,length", kats.FIND_MATCH_LENGTH)
+def test_find_match_length_kats_on_the_device(expected, s1, s2, length):   # SnappyCompressorTests.cs:10-96
+    """The reference's FindMatchLength KATs through the device function the compressor uses (wave_match_extend):
+    buffer = s1 || s2, candidate at 0, position at len(s1), fragment end = the KAT's s2Limit."""
+    import ctypes as C
+    L = S.lib()
+    buf = to_dev(np.frombuffer((s1 + s2).encode() + bytes(16), dtype=np.uint8))
+    out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = L.snp_debug_match_length(C.c_void_p(buf.data_ptr()), C.c_uint32(len(s1) + length), C.c_uint32(len(s1)), C.c_uint32(0),
+                                  C.c_uint32(0), C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and int(out.item()) == expected == O.find_match_length(s1.encode(), s2.encode(), length)
+
+
 # ------------------------------------------------------------------ compress (bit-exact against the oracle)
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -444,6 +478,28 @@ def test_stream_roundtrip(name):                                   # SnappyStrea
         assert_same(name, z.read(), data)
 
 
+def test_known_8192_byte_chunk_stress():                           # SnappyStreamTests.cs:196-216
+    """The reference's streamerrorsequence.txt fixture (hex text, 508 KB of binary): frame it, read it back in the 8192-byte
+    reads that once broke the reference's decoder, compare with the input and with the oracle's stream."""
+    import io
+    data = bytes.fromhex(read_testdata("streamerrorsequence.txt").decode("ascii").strip())
+    sink = io.BytesIO()
+    with S.SnappyStream(sink, S.CompressionMode.Compress, leaveOpen=True) as z:
+        z.write(data)
+        z.flush()
+    framed = sink.getvalue()
+    assert_same("streamerrorsequence framed", framed, O.frame_encode(data))
+    out = bytearray()
+    with S.SnappyStream(io.BytesIO(framed), S.CompressionMode.Decompress) as z:
+        while True:
+            b = z.read(8192)
+            if not b:
+                break
+            out += b
+    assert_same("streamerrorsequence rt", bytes(out), data)
+    assert_same("streamerrorsequence block", Snappy.DecompressToArray(Snappy.CompressToArray(data)), data)
+
+
 def test_stream_chunk_stress():                                    # SnappyStreamTests.cs:145-192
     """Random 1..100-byte writes with a Flush after each: hundreds of tiny chunks; every flush boundary becomes a chunk
     boundary, exactly as SnappyStreamCompressor.Flush (:82-97) does."""
@@ -636,11 +692,78 @@ def test_full_size_config2_roundtrip(codec):
     assert int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0
     assert bool((dlen == 65536).all())
     assert torch.equal(back, raw)
-    # the first 64 blocks are also pinned bit-exactly to the oracle, and block lengths repeat for a second run
-    o_len = out_len.cpu().numpy()
-    for b in range(0, 64, 8):
-        blk = raw[b * 65536:(b + 1) * 65536].cpu().numpy().tobytes()
-        assert out[b * cd.comp_stride: b * cd.comp_stride + int(o_len[b])].cpu().numpy().tobytes() == O.compress(blk)
+    _oracle_sample(cd, raw, out, out_len, nb, O.HASH_CRC32C, 1024)
     out2, _oo, out_len2, _st = cd.compress(raw, in_off, in_len, out=torch.empty_like(out))
     torch.cuda.synchronize()
     assert torch.equal(out_len, out_len2)
+
+
+def _full_size_blocks():
+    free, _total = torch.cuda.mem_get_info()
+    nb = 163840
+    need = nb * (65536 * 2 + 76512) + (3 << 30)
+    if free < need:
+        nb = int((free - (3 << 30)) // (65536 * 2 + 76512)) // 1024 * 1024
+    return nb
+
+
+def _oracle_sample(cd, raw, out, out_len, nb, variant, samples):
+    """`samples` blocks spread over the whole batch, compressed by the oracle on the host cores, compared byte for byte."""
+    idx = np.unique(np.linspace(0, nb - 1, samples).astype(np.int64))
+    sel = torch.from_numpy(idx).cuda()
+    blocks = raw.view(nb, 65536)[sel].cpu().numpy().reshape(-1)
+    off = (np.arange(len(idx), dtype=np.uint64) * np.uint64(65536))
+    ref, ref_off, ref_len, ref_st = O.compress_batch(blocks, off, np.full(len(idx), 65536, dtype=np.uint32), variant, min(os.cpu_count() or 1, 64))
+    lens = out_len.cpu().numpy()
+    assert (ref_st == 0).all() and (lens[idx] == ref_len).all()
+    for k, b in enumerate(idx):
+        got = out[b * cd.comp_stride: b * cd.comp_stride + int(lens[b])].cpu().numpy()
+        assert np.array_equal(got, ref[int(ref_off[k]): int(ref_off[k]) + int(ref_len[k])]), f"block {b}"
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("config", [3, 5])
+def test_full_size_configs_3_and_5_roundtrip(codec, config):
+    """BASELINE.json configs[2] (10 GiB low-entropy blocks) and configs[4] (one GPU's 10 GiB share of the mixed corpus) at
+    full size: decode(encode(x)) == x for every block, all status OK, 1024 blocks spread over the batch equal the oracle."""
+    nb = _full_size_blocks()
+    cd = codec[O.HASH_CRC32C]
+    if config == 3:
+        raw = SD.low_entropy_blocks(0, nb, "cuda")
+    else:
+        raw = SD.corpus_blocks([read_testdata(n) for n in CORPUS], 0, nb, SD.MIXED_SEED, "cuda")
+    in_off, in_len = cd.uniform_layout(nb)
+    out, out_off, out_len, status = cd.compress(raw, in_off, in_len)
+    back = torch.empty_like(raw)
+    dlen, dst = cd.decompress(out, out_off, out_len, back, in_off, in_len)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and bool((dlen == 65536).all())
+    assert torch.equal(back, raw)
+    _oracle_sample(cd, raw, out, out_len, nb, O.HASH_CRC32C, 1024)
+
+
+@pytest.mark.timeout(1200)
+def test_full_size_config4_framing_roundtrip(codec):
+    """BASELINE.json configs[3]: a 10 GiB stream through the framing format on the device -- encode (compress + masked
+    CRC-32C + chunk assembly), then decode with the device walking the headers and verifying every chunk CRC.  The
+    decoded stream equals the input; the first and last chunks equal the oracle's framing byte for byte."""
+    nb = _full_size_blocks()
+    cd = codec[O.HASH_CRC32C]
+    raw = SD.html_like_blocks(read_testdata("html"), 0, nb, "cuda")[: nb * 65536 - 4321]          # ragged last chunk
+    framed, written = cd.frame_encode(raw)
+    torch.cuda.synchronize()
+    w = int(written.item())
+    assert framed[:10].cpu().numpy().tobytes() == O.frame_encode(b"")[:10]
+    first = O.frame_encode(raw[:65536].cpu().numpy().tobytes())
+    assert framed[:len(first)].cpu().numpy().tobytes() == first
+    last = O.frame_encode(raw[(nb - 1) * 65536:].cpu().numpy().tobytes())[10:]
+    assert framed[w - len(last):w].cpu().numpy().tobytes() == last
+    back = torch.empty(raw.numel(), dtype=torch.uint8, device="cuda")
+    result = cd.frame_decode(framed, w, back, nb)
+    torch.cuda.synchronize()
+    assert result.cpu().tolist() == [raw.numel(), 0]
+    assert torch.equal(back, raw)
+    framed[10 + 8 + 7 + (w // 2)] ^= 0x40                                # one flipped bit somewhere in the middle of the stream
+    result = cd.frame_decode(framed, w, back, nb)
+    torch.cuda.synchronize()
+    assert result.cpu().tolist()[1] != 0
