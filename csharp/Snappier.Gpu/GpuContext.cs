@@ -1,0 +1,58 @@
+// One snp_ctx per calling thread: Snappier's static Snappy.* methods are re-entrant because they create a compressor
+// per call (Snappier/Snappy.cs:64,174,225); here the per-thread context owns a HIP stream and its HBM scratch.
+using System;
+using System.Runtime.InteropServices;
+
+namespace Snappier.Gpu;
+
+public sealed class GpuContext : SafeHandle
+{
+    [ThreadStatic] private static GpuContext? t_current;
+
+    /// <summary>Device ordinal and hash variant new per-thread contexts are created with.</summary>
+    public static int DefaultDevice { get; set; }
+    public static SnpHash DefaultHash { get; set; } = SnpHash.Crc32C;
+
+    private GpuContext() : base(IntPtr.Zero, ownsHandle: true) { }
+
+    public override bool IsInvalid => handle == IntPtr.Zero;
+
+    /// <summary>False when no HIP device is usable: callers keep the managed Snappier path (there is no CPU fallback in the library).</summary>
+    public static bool IsAvailable => TryGetCurrent(out _);
+
+    public static GpuContext Current =>
+        TryGetCurrent(out GpuContext? c) ? c! : throw new InvalidOperationException("libsnappier_hip: no HIP device (snp_ctx_create returned Device)");
+
+    public static bool TryGetCurrent(out GpuContext? ctx)
+    {
+        ctx = t_current;
+        if (ctx is { IsInvalid: false, IsClosed: false }) return true;
+        ctx = Create(DefaultDevice, DefaultHash);
+        t_current = ctx;
+        return ctx is not null;
+    }
+
+    public static GpuContext? Create(int device, SnpHash hash, IntPtr hipStream = default)
+    {
+        SnpStatus st;
+        try { st = NativeMethods.snp_ctx_create(device, (int)hash, hipStream, out IntPtr h); if (st == SnpStatus.Ok) { var c = new GpuContext(); c.SetHandle(h); return c; } }
+        catch (DllNotFoundException) { }
+        catch (EntryPointNotFoundException) { }
+        return null;
+    }
+
+    public string LastError => Marshal.PtrToStringUTF8(NativeMethods.snp_ctx_last_error(handle)) ?? string.Empty;
+
+    /// <summary>which: 0 large blocks decoded one wavefront per 64 KiB fragment, 1 fell back to one wavefront, 2/3 workspace probe.</summary>
+    public ulong Counter(int which) => NativeMethods.snp_ctx_counter(handle, which);
+
+    public void Synchronize() => Snappy.ThrowIfFailed(NativeMethods.snp_ctx_synchronize(handle));
+
+    internal IntPtr Handle => handle;
+
+    protected override bool ReleaseHandle()
+    {
+        NativeMethods.snp_ctx_destroy(handle);
+        return true;
+    }
+}

@@ -1,0 +1,192 @@
+/*
+ * abi_conformance.c -- the drop-in boundary seen from the FOREIGN side: plain C, dlopen, no HIP, no Python.
+ * It makes exactly the calls csharp/Snappier.Gpu makes (NativeMethods.cs: symbol names, argument order and widths;
+ * Snappy.cs / SnappyStreamChunkCodec.cs: call sequences and the status codes they branch on), so the C# shim's
+ * assumptions are tested even though no .NET toolchain exists in the build image.
+ *
+ *   abi_conformance <libsnappier_hip.so> host      host-only part (no device needed): every symbol resolves, enum values,
+ *                                                  length arithmetic, varint KATs, snp_ctx_create -> SNP_ERR_DEVICE or SNP_OK
+ *   abi_conformance <libsnappier_hip.so> device <datafile>   the full call sequences on a GPU, round trips compared
+ * Exit code 0 = conforming; every failed expectation prints a line and counts.
+ * TEST INFRASTRUCTURE.
+ */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/snappier_hip.h"
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                                     \
+    do {                                                                                 \
+        if (!(cond)) { printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); ++g_fail; } \
+    } while (0)
+
+/* the values csharp/Snappier.Gpu/NativeMethods.cs hard-codes (enum SnpStatus / SnpHash, constants) */
+_Static_assert(SNP_OK == 0 && SNP_ERR_OUTPUT_TOO_SMALL == 1 && SNP_ERR_BAD_OFFSET == 2 && SNP_ERR_TOO_LONG == 3 &&
+               SNP_ERR_INCOMPLETE == 4 && SNP_ERR_BAD_LENGTH == 5 && SNP_ERR_CRC_MISMATCH == 6 && SNP_ERR_CHUNK_TYPE == 7 &&
+               SNP_ERR_OVERLAP == 8 && SNP_ERR_BAD_ARG == 9 && SNP_ERR_DEVICE == 10 && SNP_ERR_TRUNCATED_STREAM == 11,
+               "SnpStatus values");
+_Static_assert(SNP_HASH_CRC32C == 0 && SNP_HASH_MUL == 1, "SnpHash values");
+_Static_assert(SNP_BLOCK_SIZE == 65536 && SNP_MAX_BLOCK_COMPRESSED == 76491 && SNP_VARINT_MAX == 5 &&
+               SNP_STREAM_HEADER_LEN == 10 && SNP_CHUNK_HEADER_LEN == 8, "constants");
+_Static_assert(sizeof(snp_status) == 4 && sizeof(size_t) == 8 && sizeof(void*) == 8, "int32 status, 64-bit size_t (nuint)");
+
+/* one function-pointer type per DllImport, spelled with the C types the C# marshaller produces */
+typedef int32_t (*fn_ctx_create)(int32_t, int32_t, void*, void**);
+typedef void (*fn_ctx_destroy)(void*);
+typedef int32_t (*fn_ctx_set_stream)(void*, void*);
+typedef const char* (*fn_ctx_last_error)(const void*);
+typedef int32_t (*fn_ctx_synchronize)(void*);
+typedef uint64_t (*fn_ctx_counter)(const void*, int32_t);
+typedef const char* (*fn_status_string)(int32_t);
+typedef const char* (*fn_version)(void);
+typedef int64_t (*fn_len)(int64_t);
+typedef int32_t (*fn_get_ulen)(const uint8_t*, size_t, uint32_t*, uint32_t*);
+typedef int32_t (*fn_buf)(void*, const uint8_t*, size_t, uint8_t*, size_t, size_t*);
+typedef int32_t (*fn_crc)(void*, const uint8_t*, size_t, int32_t, uint32_t*);
+typedef int32_t (*fn_frame_len)(const uint8_t*, size_t, uint64_t*);
+
+static void* must(void* lib, const char* name)
+{
+    void* p = dlsym(lib, name);
+    if (!p) { printf("FAIL missing symbol %s\n", name); ++g_fail; }
+    return p;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) { fprintf(stderr, "usage: %s <lib> host|device [datafile]\n", argv[0]); return 2; }
+    void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { printf("FAIL dlopen: %s\n", dlerror()); return 1; }
+    const int device = strcmp(argv[2], "device") == 0;
+
+    /* every DllImport of NativeMethods.cs must resolve */
+    static const char* all[] = {
+        "snp_ctx_create", "snp_ctx_destroy", "snp_ctx_set_stream", "snp_ctx_last_error", "snp_ctx_synchronize", "snp_ctx_counter",
+        "snp_status_string", "snp_version", "snp_max_compressed_length", "snp_max_fragment_compressed_length",
+        "snp_get_uncompressed_length", "snp_try_compress", "snp_try_decompress", "snp_crc32c", "snp_frame_max_encoded_length",
+        "snp_frame_encode", "snp_frame_decoded_length", "snp_frame_decode", "snp_compress_batch", "snp_decompress_batch",
+        "snp_crc32c_batch", "snp_concat_batch", "snp_frame_encode_workspace", "snp_frame_encode_device",
+        "snp_frame_decode_chunks_device", "snp_frame_decode_workspace", "snp_frame_decode_device"};
+    for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i) (void)must(lib, all[i]);
+    if (g_fail) return 1;
+
+    fn_ctx_create ctx_create = (fn_ctx_create)must(lib, "snp_ctx_create");
+    fn_ctx_destroy ctx_destroy = (fn_ctx_destroy)must(lib, "snp_ctx_destroy");
+    fn_ctx_last_error last_error = (fn_ctx_last_error)must(lib, "snp_ctx_last_error");
+    fn_ctx_counter counter = (fn_ctx_counter)must(lib, "snp_ctx_counter");
+    fn_status_string status_string = (fn_status_string)must(lib, "snp_status_string");
+    fn_version version = (fn_version)must(lib, "snp_version");
+    fn_len max_len = (fn_len)must(lib, "snp_max_compressed_length");
+    fn_len max_frag = (fn_len)must(lib, "snp_max_fragment_compressed_length");
+    fn_len frame_max = (fn_len)must(lib, "snp_frame_max_encoded_length");
+    fn_get_ulen get_ulen = (fn_get_ulen)must(lib, "snp_get_uncompressed_length");
+    fn_buf try_compress = (fn_buf)must(lib, "snp_try_compress");
+    fn_buf try_decompress = (fn_buf)must(lib, "snp_try_decompress");
+    fn_buf frame_encode = (fn_buf)must(lib, "snp_frame_encode");
+    fn_buf frame_decode = (fn_buf)must(lib, "snp_frame_decode");
+    fn_crc crc32c = (fn_crc)must(lib, "snp_crc32c");
+    fn_frame_len frame_decoded_length = (fn_frame_len)must(lib, "snp_frame_decoded_length");
+
+    /* ---- host-only: what Snappy.GetMaxCompressedLength / GetUncompressedLength / ThrowIfFailed rely on -------------- */
+    EXPECT(max_len(65536) == 76496 && max_frag(65536) == 76491 && max_len(0) == 38 && max_len(-1) == -1);
+    EXPECT(frame_max(0) == 10 && frame_max(65537) == 10 + 16 + 65537);
+    EXPECT(strcmp(status_string(SNP_ERR_OUTPUT_TOO_SMALL), "Output buffer is too small.") == 0);
+    EXPECT(strcmp(status_string(SNP_ERR_BAD_OFFSET), "Invalid copy offset") == 0);
+    EXPECT(strcmp(status_string(SNP_ERR_TOO_LONG), "Data too long") == 0);
+    EXPECT(strcmp(status_string(SNP_ERR_INCOMPLETE), "Incomplete Snappy block.") == 0);
+    EXPECT(strcmp(status_string(SNP_ERR_BAD_LENGTH), "Invalid stream length") == 0);
+    EXPECT(strcmp(status_string(SNP_ERR_CRC_MISMATCH), "Chunk CRC mismatch.") == 0);
+    EXPECT(strcmp(status_string(SNP_ERR_OVERLAP), "Input and output spans must not overlap.") == 0);
+    EXPECT(version() && strstr(version(), "snappier_hip") != NULL);
+    {
+        const uint8_t v1[] = {0x80, 0x80, 0x04, 0xff};                   /* 65536 */
+        const uint8_t bad[] = {0xff, 0xff, 0xff, 0xff, 0x7f, 0x00};      /* overflow in the 5th byte */
+        const uint8_t cut[] = {0x80, 0x80};
+        uint32_t n = 0, hb = 0;
+        EXPECT(get_ulen(v1, sizeof v1, &n, &hb) == SNP_OK && n == 65536 && hb == 3);
+        EXPECT(get_ulen(bad, sizeof bad, &n, &hb) == SNP_ERR_BAD_LENGTH);
+        EXPECT(get_ulen(cut, sizeof cut, &n, &hb) == SNP_ERR_BAD_LENGTH);
+        EXPECT(get_ulen(v1, 0, &n, &hb) == SNP_ERR_BAD_LENGTH);
+        uint64_t total = 1;
+        const uint8_t hdr_only[] = {0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59};
+        EXPECT(frame_decoded_length(hdr_only, sizeof hdr_only, &total) == SNP_OK && total == 0);
+    }
+    void* ctx = NULL;
+    EXPECT(ctx_create(0, 7, NULL, &ctx) == SNP_ERR_BAD_ARG && ctx == NULL);      /* unknown hash variant */
+    const int32_t st_create = ctx_create(0, SNP_HASH_CRC32C, NULL, &ctx);
+    if (!device) {
+        /* GpuContext.Create: Ok -> usable, Device -> IsAvailable == false (managed fallback); nothing else is acceptable */
+        EXPECT(st_create == SNP_OK || (st_create == SNP_ERR_DEVICE && ctx == NULL));
+        if (ctx) ctx_destroy(ctx);
+        printf("%s (host part, ctx_create -> %d)\n", g_fail ? "NOT CONFORMING" : "conforming", st_create);
+        return g_fail ? 1 : 0;
+    }
+    EXPECT(st_create == SNP_OK && ctx != NULL);
+    if (!ctx) return 1;
+    EXPECT(last_error(ctx) != NULL);
+
+    /* ---- device: the sequences of Snappy.cs ------------------------------------------------------------------ */
+    FILE* f = argc > 3 ? fopen(argv[3], "rb") : NULL;
+    if (!f) { printf("FAIL cannot open data file\n"); return 1; }
+    static uint8_t data[300000];
+    const size_t n = fread(data, 1, sizeof data, f);
+    fclose(f);
+    EXPECT(n > 70000);
+    const size_t cap = (size_t)max_len((int64_t)n);
+    uint8_t* comp = malloc(cap);
+    uint8_t* back = malloc(n + 16);
+    size_t w = 123, w2 = 0;
+    /* TryCompress: empty / too-small output -> false, bytesWritten 0 */
+    EXPECT(try_compress(ctx, data, n, comp, 0, &w) == SNP_ERR_OUTPUT_TOO_SMALL && w == 0);
+    EXPECT(try_compress(ctx, data, n, comp, 10, &w) == SNP_ERR_OUTPUT_TOO_SMALL && w == 0);
+    /* overlap -> InvalidOperationException */
+    EXPECT(try_compress(ctx, data, 1000, data + 500, 2000, &w) == SNP_ERR_OVERLAP);
+    /* Compress into GetMaxCompressedLength, then into exactly the compressed length (SnappyTests.cs:41-63) */
+    EXPECT(try_compress(ctx, data, n, comp, cap, &w) == SNP_OK && w > 3 && w < n);
+    uint8_t* exact = malloc(w);
+    EXPECT(try_compress(ctx, data, n, exact, w, &w2) == SNP_OK && w2 == w && memcmp(exact, comp, w) == 0);
+    EXPECT(try_compress(ctx, data, n, exact, w - 1, &w2) == SNP_ERR_OUTPUT_TOO_SMALL && w2 == 0);
+    /* DecompressToMemory: GetUncompressedLength sizes the buffer, TryDecompress fills it */
+    uint32_t ulen = 0, hb = 0;
+    EXPECT(get_ulen(comp, w, &ulen, &hb) == SNP_OK && ulen == n);
+    EXPECT(try_decompress(ctx, comp, w, back, n, &w2) == SNP_OK && w2 == n && memcmp(back, data, n) == 0);
+    EXPECT(try_decompress(ctx, comp, w, back, n - 1, &w2) == SNP_ERR_OUTPUT_TOO_SMALL && w2 == 0);
+    EXPECT(counter(ctx, 0) + counter(ctx, 1) >= 1);                      /* n >= 256 KiB took the per-fragment path or its fallback */
+    /* corrupt data -> InvalidDataException family */
+    EXPECT(try_decompress(ctx, comp, w / 2, back, n, &w2) == SNP_ERR_INCOMPLETE);
+    {
+        uint8_t junk[8] = {0x08, 0x0c, 'a', 'b', 'c', 'd', 0x05, 0x09};  /* declared 8: literal "abcd" then a copy with offset 9 > 4 */
+        EXPECT(try_decompress(ctx, junk, sizeof junk, back, 8, &w2) == SNP_ERR_BAD_OFFSET);
+    }
+    /* one small buffer (a single fragment, the Snappy.CompressToArray("hello") case) */
+    EXPECT(try_compress(ctx, (const uint8_t*)"hello hello hello hello", 23, comp, cap, &w) == SNP_OK);
+    EXPECT(try_decompress(ctx, comp, w, back, 23, &w2) == SNP_OK && w2 == 23 && memcmp(back, "hello hello hello hello", 23) == 0);
+    /* empty input: one preamble byte */
+    EXPECT(try_compress(ctx, data, 0, comp, cap, &w) == SNP_OK && w == 1 && comp[0] == 0);
+    EXPECT(try_decompress(ctx, comp, 1, back, 0 + 1, &w2) == SNP_OK && w2 == 0);
+
+    /* ---- device: the sequences of SnappyStreamChunkCodec.cs ----------------------------------------------------- */
+    const size_t fcap = (size_t)frame_max((int64_t)n);
+    uint8_t* framed = malloc(fcap);
+    EXPECT(frame_encode(ctx, data, n, framed, fcap, &w) == SNP_OK && w > 18 && memcmp(framed, "\xff\x06\x00\x00sNaPpY", 10) == 0);
+    uint64_t total = 0;
+    EXPECT(frame_decoded_length(framed, w, &total) == SNP_OK && total == n);
+    EXPECT(frame_decode(ctx, framed, w, back, n, &w2) == SNP_OK && w2 == n && memcmp(back, data, n) == 0);
+    EXPECT(frame_decode(ctx, framed + 10, w - 10, back, n, &w2) == SNP_OK && w2 == n);   /* a run of chunks without the identifier */
+    framed[14] ^= 1;                                                     /* first chunk's CRC */
+    EXPECT(frame_decode(ctx, framed, w, back, n, &w2) == SNP_ERR_CRC_MISMATCH);
+    framed[14] ^= 1;
+    framed[10] = 0x02;                                                   /* reserved unskippable chunk type */
+    EXPECT(frame_decode(ctx, framed, w, back, n, &w2) == SNP_ERR_CHUNK_TYPE);
+    framed[10] = 0x00;
+    uint32_t crc = 0;
+    EXPECT(crc32c(ctx, (const uint8_t*)"123456789", 9, 0, &crc) == SNP_OK && crc == 0xE3069283u);   /* Crc32CAlgorithmTests.cs */
+    ctx_destroy(ctx);
+    free(comp); free(back); free(exact); free(framed);
+    printf("%s (device part)\n", g_fail ? "NOT CONFORMING" : "conforming");
+    return g_fail ? 1 : 0;
+}
