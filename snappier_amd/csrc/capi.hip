@@ -34,6 +34,8 @@ hipError_t snp_launch_frame_plan(const u32*, const u32*, u32, u8*, u32*, u64*, u
 hipError_t snp_launch_frame_header_only(u8*, u64*, hipStream_t);
 hipError_t snp_launch_frame_scan(const u8*, u64, u64, u32, u8*, u64*, u32*, u32*, u64*, u32*, u64*, hipStream_t);
 hipError_t snp_launch_frame_result(const i32*, const u64*, u64*, hipStream_t);
+size_t snp_frame_scan_workspace(u64);
+hipError_t snp_launch_frame_scan_spans(const u8*, u64, u64, u32, u8*, u64*, u32*, u32*, u64*, u32*, u64*, void*, hipStream_t);
 hipError_t snp_launch_frame_emit(const u8*, const u64*, const u8*, const u64*, const u8*, const u32*, const u32*,
                                  const u64*, u8*, u64, u32, hipStream_t);
 }
@@ -66,7 +68,8 @@ struct snp_ctx {
                              // (compress_lanes.hip), 3 wave-per-fragment multi-token windows (compress_win.hip)
     int win_np = 1;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2; 2 measured slower)
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
-    DevBuf in, out, meta, work, tables;
+    DevBuf in, out, meta, work, tables, scan;
+    int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
     uint64_t counters[4] = {0, 0, 0, 0};   // snp_ctx_counter
     std::string err;
 
@@ -224,6 +227,8 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : (cm && strncmp(cm, "win", 3) == 0) ? 3 : 0;
     const char* wn = getenv("SNAPPIER_HIP_WIN_NP");
     if (wn) c->win_np = atoi(wn) == 2 ? 2 : 1;
+    const char* fs = getenv("SNAPPIER_HIP_FRAME_SCAN");
+    c->frame_scan = (fs && strcmp(fs, "serial") == 0) ? 1 : 0;
     const char* wm = getenv("SNAPPIER_HIP_WIN_MAX");
     if (wm) c->win_max = static_cast<u32>(strtoul(wm, nullptr, 10));
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
@@ -244,7 +249,7 @@ void snp_ctx_destroy(snp_ctx* c)
     {
         DevGuard dg(c);
         (void)hipStreamSynchronize(c->stream);
-        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables})
+        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan})
             if (b->p) (void)hipFree(b->p);
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -486,8 +491,15 @@ snp_status snp_frame_decode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, 
     u32* out_len = out_cap + max_chunks;
     i32* status = reinterpret_cast<i32*>(out_len + max_chunks);
     u8* type = reinterpret_cast<u8*>(status + max_chunks);
-    bool ok = c->check(snp_launch_frame_scan(d_in, n, cap, max_chunks, type, body_off, body_len, crc, out_off, out_cap, hdr, s),
-                       "frame scan");
+    bool ok;
+    if (c->frame_scan == 1) {
+        ok = c->check(snp_launch_frame_scan(d_in, n, cap, max_chunks, type, body_off, body_len, crc, out_off, out_cap, hdr, s), "frame scan");
+    } else {
+        // per-span candidate tables live in context scratch (a few MB per 10 GiB of stream; grows on first use only)
+        if (!c->ensure(c->scan, snp_frame_scan_workspace(n), "hipMalloc(frame scan)")) return SNP_ERR_DEVICE;
+        ok = c->check(snp_launch_frame_scan_spans(d_in, n, cap, max_chunks, type, body_off, body_len, crc, out_off, out_cap, hdr,
+                                                  c->scan.p, s), "frame scan (spans)");
+    }
     if (ok && max_chunks && n) {                     // n == 0: no chunk, nothing to launch
         const snp_status st = snp_frame_decode_chunks_device(c, d_in, type, body_off, body_len, crc, max_chunks, d_out, out_off,
                                                              out_cap, out_len, status);

@@ -671,6 +671,82 @@ def test_frame_decode_device_walks_the_headers_itself(codec):
     assert st == 0 and got == raw
 
 
+@pytest.mark.parametrize("scan", ["spans", "serial"])
+def test_frame_decode_device_span_walk(scan, monkeypatch):
+    """The concurrent header walk (frame_scan.hip: 1 MiB spans, candidate entry points, resolver, emitter) against the
+    oracle and against the one-lane walk on streams built to hit its corners: chunks straddling span boundaries, a
+    skippable chunk larger than several spans, raw payloads full of fake chunk headers, hundreds of tiny chunks (more
+    candidates than a span keeps), errors deep in the stream, a full chunk table, a short output buffer."""
+    monkeypatch.setenv("SNAPPIER_HIP_FRAME_SCAN", scan)
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    rng = np.random.default_rng(2)
+
+    def chunk(t, body):
+        return bytes([t]) + len(body).to_bytes(3, "little") + body
+
+    def data_chunks(raw):                      # the oracle's chunks for raw, without the stream identifier
+        return O.frame_encode(raw)[10:]
+
+    html, jpeg = read_testdata("html"), read_testdata("fireworks.jpeg")
+    fake = b"".join(chunk(1, bytes(4) + bytes(60)) + chunk(0, bytes(4) + bytes([40]) + bytes(30)) for _ in range(300))
+    pieces = [O.frame_encode(b"")]
+    raws = []
+    def add(raw):
+        raws.append(raw)
+        pieces.append(data_chunks(raw))
+    add(html * 9)                                                   # ~0.9 MiB of compressed chunks: crosses the first span boundary
+    add(jpeg * 9)                                                   # incompressible: raw (type 1) chunks
+    pieces.append(chunk(0x99, rng.integers(0, 256, 2_600_000, dtype=np.uint8).tobytes()))   # skippable, larger than two spans
+    add(fake[:65536] * 20)                                          # raw-looking payload that is full of plausible headers
+    add(bytes(rng.integers(0, 256, 65536 * 18, dtype=np.uint8)))    # raw chunks again, random bytes
+    for k in range(400):                                            # hundreds of tiny chunks: > 4 candidates per window
+        add(bytes([k & 255]) * (1 + k % 7))
+        if k % 50 == 0:
+            pieces.append(chunk(0xfe, bytes(k)))                    # padding
+    pieces.append(O.frame_encode(b""))                              # a repeated stream identifier
+    add(html[:70000])
+    stream = b"".join(pieces)
+    raw = b"".join(raws)
+    assert len(stream) > 4 * (1 << 20)
+    nchunks = sum((len(r) + 65535) // 65536 for r in raws)
+
+    def run(st, cap=None, max_chunks=None):
+        fr = to_dev(np.frombuffer(st, dtype=np.uint8))
+        out = torch.zeros(len(raw) + 64 if cap is None else cap, dtype=torch.uint8, device="cuda")
+        res = cd.frame_decode(fr, len(st), out, nchunks + 8 if max_chunks is None else max_chunks)
+        torch.cuda.synchronize()
+        written, status = (int(v) for v in res.cpu().tolist())
+        return out[:written].cpu().numpy().tobytes(), status
+
+    got, st = run(stream)
+    assert st == 0
+    assert_same(f"span walk {scan}", got, raw)
+    assert_same(f"span walk {scan} oracle", O.frame_decode(stream), raw)
+    assert run(stream, max_chunks=nchunks)[1] == 0                   # exactly as many rows as chunks
+    assert run(stream, max_chunks=nchunks - 1)[1] == O.ERR_OUTPUT_TOO_SMALL
+    assert run(stream, max_chunks=7)[1] == O.ERR_OUTPUT_TOO_SMALL
+    assert run(stream, cap=len(raw) - 1)[1] == O.ERR_OUTPUT_TOO_SMALL
+    # errors far into the stream: status as the oracle, nothing returned
+    cut = len(stream) - 33333
+    for name, bad in (("truncated", stream[:cut]), ("truncated in header", stream[:len(stream) - len(data_chunks(html[:70000])) + 2]),
+                      ("reserved chunk type", stream[:-len(data_chunks(html[:70000]))] + chunk(0x33, b"x") + data_chunks(html[:70000]))):
+        try:
+            O.frame_decode(bad)
+            want = 0
+        except O.OracleError as e:
+            want = e.status
+        got, st = run(bad)
+        assert want != 0 and st == want and got == b"", (scan, name, st, want)
+    flipped = bytearray(stream)
+    flipped[len(stream) // 2] ^= 0x10                                # lands in a chunk body or header somewhere in the middle
+    try:
+        O.frame_decode(bytes(flipped))
+        want = 0
+    except O.OracleError as e:
+        want = e.status
+    assert run(bytes(flipped))[1] == want
+
+
 # ------------------------------------------------------------------ full BASELINE size, size-independent properties
 
 @pytest.mark.timeout(1200)
