@@ -4,10 +4,14 @@
 // There is no CPU fallback -- without a HIP device snp_ctx_create fails with SNP_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "snp_device.h"
@@ -53,6 +57,70 @@ struct DevBuf {
 inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 }  // namespace
+
+// ---- host <-> device transfers of the host-pointer entry points --------------------------------------------------
+// The reference's Span API hands over pageable memory.  Optional path (SNAPPIER_HIP_PINNED=1): three context-owned PINNED
+// slices, DMA of slice i+1, i+2 in flight while worker threads memcpy slice i between the pinned slice and the caller's
+// buffer.  Default is the runtime's own pageable hipMemcpy, which measured faster (see ensure_pipe).
+class CopyPool {
+public:
+    explicit CopyPool(unsigned nthreads)
+    {
+        for (unsigned t = 0; t < nthreads; ++t) workers_.emplace_back([this] { run(); });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    // memcpy split over the workers (and the caller); returns when every byte is copied
+    void copy(void* dst, const void* src, size_t n)
+    {
+        const size_t parts = workers_.size() + 1;
+        const size_t piece = ((n + parts - 1) / parts + 4095) & ~static_cast<size_t>(4095);
+        if (n < (1u << 20) || workers_.empty()) { memcpy(dst, src, n); return; }
+        size_t mine_off = 0, mine_len = piece < n ? piece : n;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (size_t off = piece; off < n; off += piece) {
+                jobs_.push_back({static_cast<u8*>(dst) + off, static_cast<const u8*>(src) + off, off + piece < n ? piece : n - off});
+                ++pending_;
+            }
+        }
+        cv_.notify_all();
+        memcpy(static_cast<u8*>(dst) + mine_off, static_cast<const u8*>(src) + mine_off, mine_len);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+private:
+    struct Job { u8* d; const u8* s; size_t n; };
+    void run()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return quit_ || !jobs_.empty(); });
+                if (quit_ && jobs_.empty()) return;
+                j = jobs_.back();
+                jobs_.pop_back();
+            }
+            memcpy(j.d, j.s, j.n);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::vector<Job> jobs_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    size_t pending_ = 0;
+    bool quit_ = false;
+};
 
 struct snp_ctx {
     int device = 0;
@@ -131,6 +199,73 @@ struct snp_ctx {
         b.cap = want;
         return true;
     }
+    // ---- pipelined transfers (see CopyPool) -------------------------------------------------------------------------
+    static constexpr size_t kSlice = 32u << 20;      // bytes per pinned slice
+    static constexpr size_t kPipeMin = 8u << 20;     // smaller transfers go straight through hipMemcpyAsync
+    void* pin[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t pin_ev[3] = {nullptr, nullptr, nullptr};
+    CopyPool* pool = nullptr;
+    int pipe_state = 0;                              // 0 untried, 1 ready, -1 unavailable (plain copies)
+    bool ensure_pipe()
+    {
+        if (pipe_state) return pipe_state > 0;
+        // Measured on the MI355X box (profiles/r02b_host_api_rates.jsonl): the runtime's own pageable path already moves
+        // 1 GiB at ~40 GB/s, FASTER than this pipeline (31 GB/s: the worker memcpys are the slow leg).  So it is opt-in.
+        const char* on = getenv("SNAPPIER_HIP_PINNED");
+        pipe_state = -1;
+        if (!on || on[0] != '1') return false;
+        for (int k = 0; k < 3; ++k) {
+            if (hipHostMalloc(&pin[k], kSlice, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin[k] = nullptr; return false; }
+            if (hipEventCreateWithFlags(&pin_ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
+        unsigned hw = std::thread::hardware_concurrency();
+        const char* th = getenv("SNAPPIER_HIP_COPY_THREADS");
+        unsigned nt = th ? static_cast<unsigned>(atoi(th)) : (hw >= 32 ? 7u : hw >= 8 ? 3u : 1u);
+        pool = new (std::nothrow) CopyPool(nt > 31 ? 31 : nt);
+        if (!pool) return false;
+        pipe_state = 1;
+        return true;
+    }
+    // host -> device, n bytes; on return the caller's buffer has been read completely (copies may still be in flight on `stream`)
+    bool h2d(void* dev, const void* host, size_t n, const char* what)
+    {
+        if (n < kPipeMin || !ensure_pipe()) return check(hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, stream), what);
+        size_t i = 0;
+        for (size_t off = 0; off < n; off += kSlice, ++i) {
+            const size_t len = n - off < kSlice ? n - off : kSlice;
+            const int b = static_cast<int>(i % 3);
+            if (i >= 3 && !check(hipEventSynchronize(pin_ev[b]), what)) return false;      // the DMA that last read this slice
+            pool->copy(pin[b], static_cast<const u8*>(host) + off, len);
+            if (!check(hipMemcpyAsync(static_cast<u8*>(dev) + off, pin[b], len, hipMemcpyHostToDevice, stream), what)) return false;
+            if (!check(hipEventRecord(pin_ev[b], stream), what)) return false;
+        }
+        // later users of the slices (another h2d/d2h) must not overwrite them before these DMAs have read them
+        return check(hipStreamSynchronize(stream), what);
+    }
+    // device -> host, n bytes, ordered after everything queued on `stream`; returns when the bytes are in the caller's buffer
+    bool d2h(void* host, const void* dev, size_t n, const char* what)
+    {
+        if (n < kPipeMin || !ensure_pipe())
+            return check(hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, stream), what) && check(hipStreamSynchronize(stream), what);
+        const size_t slices = (n + kSlice - 1) / kSlice;
+        auto issue = [&](size_t i) {
+            const size_t off = i * kSlice, len = n - off < kSlice ? n - off : kSlice;
+            const int b = static_cast<int>(i % 3);
+            return check(hipMemcpyAsync(pin[b], static_cast<const u8*>(dev) + off, len, hipMemcpyDeviceToHost, stream), what) &&
+                   check(hipEventRecord(pin_ev[b], stream), what);
+        };
+        for (size_t i = 0; i < slices && i < 2; ++i)
+            if (!issue(i)) return false;
+        for (size_t j = 0; j < slices; ++j) {
+            const size_t off = j * kSlice, len = n - off < kSlice ? n - off : kSlice;
+            const int b = static_cast<int>(j % 3);
+            if (!check(hipEventSynchronize(pin_ev[b]), what)) return false;
+            if (j + 2 < slices && !issue(j + 2)) return false;                              // slice (j+2)%3 was drained at step j-1
+            pool->copy(static_cast<u8*>(host) + off, pin[b], len);
+        }
+        return true;
+    }
+
     // The hash-table workspace of the lane compressor.  Large ones are placement-sensitive (compress_lanes.hip,
     // snp_probe_tables): allocate up to `table_tries` candidates, keep the one HBM serves fastest.
     bool ensure_tables(u32 nblocks)
@@ -252,6 +387,11 @@ void snp_ctx_destroy(snp_ctx* c)
         for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan})
             if (b->p) (void)hipFree(b->p);
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+        delete c->pool;
+        for (int k = 0; k < 3; ++k) {
+            if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]);
+            if (c->pin[k]) (void)hipHostFree(c->pin[k]);
+        }
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -550,7 +690,7 @@ snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
     u32* d_comp_len = d_in_len + nf;
     i32* d_status = reinterpret_cast<i32*>(d_comp_len + nf);
 
-    bool ok = c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    bool ok = c->h2d(c->in.p, in, n, "H2D input");
     ok = ok && c->check(snp_launch_frame_chunks(n, nf, kCompStride, d_in_off, d_in_len, d_comp_off, s), "fragment table");
     ok = ok && c->launch_compress(static_cast<const u8*>(c->in.p), d_in_off, d_in_len, nf, static_cast<u8*>(c->work.p),
                                   d_comp_off, d_comp_len, d_status, 0);
@@ -567,7 +707,7 @@ snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
     ok = c->check(hipMemcpyAsync(d_dst_off, dst_off.data(), nf * 8ull, hipMemcpyHostToDevice, s), "H2D offsets");
     ok = ok && c->check(snp_launch_gather(static_cast<const u8*>(c->work.p), d_comp_off, d_comp_len,
                                           static_cast<u8*>(c->out.p), d_dst_off, nf, s), "gather");
-    ok = ok && c->check(hipMemcpyAsync(out + hb, c->out.p, total, hipMemcpyDeviceToHost, s), "D2H output");
+    ok = ok && c->d2h(out + hb, c->out.p, total, "D2H output");
     ok = ok && c->check(hipStreamSynchronize(s), "sync");
     if (!ok) return SNP_ERR_DEVICE;
     memcpy(out, hdr, hb);
@@ -590,7 +730,7 @@ snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* 
     struct Meta { u64 in_off, out_off; u32 in_len, out_cap, out_len; i32 status; } h{0, 0, static_cast<u32>(n), cap32, 0, 0};
     u8* m = static_cast<u8*>(c->meta.p);
     bool ok = c->check(hipMemcpyAsync(m, &h, sizeof(h), hipMemcpyHostToDevice, s), "H2D meta");
-    if (n) ok = ok && c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    if (n) ok = ok && c->h2d(c->in.p, in, n, "H2D input");
 
     // A large block: one wavefront per 64 KiB output fragment, fragment starts from the tag index (tag_index.hip).
     // Taken only for a clean preamble that fits the output; any fragment that does not come back OK (foreign streams
@@ -650,7 +790,7 @@ snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* 
                     if (st[f] != SNP_OK) { fprintf(stderr, "   fragment %u: status %d in_off %llu in_len %u skip %u\n", f, st[f], (unsigned long long)fo[f], il[f], sk[f]); ++shown; }
             }
             if (all_ok) {
-                ok = c->check(hipMemcpyAsync(out, c->out.p, expected, hipMemcpyDeviceToHost, s), "D2H output") &&
+                ok = c->d2h(out, c->out.p, expected, "D2H output") &&
                      c->check(hipStreamSynchronize(s), "sync");
                 if (!ok) return SNP_ERR_DEVICE;
                 *written = expected;
@@ -670,7 +810,7 @@ snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* 
     if (!ok) return SNP_ERR_DEVICE;
     if (h.status != SNP_OK) return static_cast<snp_status>(h.status);
     if (h.out_len) {
-        ok = c->check(hipMemcpyAsync(out, c->out.p, h.out_len, hipMemcpyDeviceToHost, s), "D2H output") &&
+        ok = c->d2h(out, c->out.p, h.out_len, "D2H output") &&
              c->check(hipStreamSynchronize(s), "sync");
         if (!ok) return SNP_ERR_DEVICE;
     }
@@ -689,7 +829,7 @@ snp_status snp_crc32c(snp_ctx* c, const uint8_t* in, size_t n, int masked, uint3
     struct Meta { u64 off; u32 len, crc; } h{0, static_cast<u32>(n), 0};
     u8* m = static_cast<u8*>(c->meta.p);
     bool ok = c->check(hipMemcpyAsync(m, &h, sizeof(h), hipMemcpyHostToDevice, s), "H2D meta");
-    if (n) ok = ok && c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    if (n) ok = ok && c->h2d(c->in.p, in, n, "H2D input");
     ok = ok && c->check(snp_launch_crc32c(static_cast<const u8*>(c->in.p), reinterpret_cast<u64*>(m), reinterpret_cast<u32*>(m + 8),
                                           1, masked, reinterpret_cast<u32*>(m + 12), nullptr, nullptr, s), "crc32c");
     ok = ok && c->check(hipMemcpyAsync(&h, m, sizeof(h), hipMemcpyDeviceToHost, s), "D2H meta");
@@ -713,7 +853,7 @@ snp_status snp_frame_encode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
         !c->ensure(c->work, wbytes + 16, "hipMalloc(work)") || !c->ensure(c->meta, 64, "hipMalloc(meta)"))
         return SNP_ERR_DEVICE;
     bool ok = true;
-    if (n) ok = c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    if (n) ok = c->h2d(c->in.p, in, n, "H2D input");
     if (!ok) return SNP_ERR_DEVICE;
     snp_status st = snp_frame_encode_device(c, static_cast<const u8*>(c->in.p), n, static_cast<u8*>(c->out.p), max_out,
                                             static_cast<u64*>(c->meta.p), c->work.p);
@@ -723,7 +863,7 @@ snp_status snp_frame_encode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
          c->check(hipStreamSynchronize(s), "sync");
     if (!ok) return SNP_ERR_DEVICE;
     if (total > cap) return SNP_ERR_OUTPUT_TOO_SMALL;
-    ok = c->check(hipMemcpyAsync(out, c->out.p, total, hipMemcpyDeviceToHost, s), "D2H output") &&
+    ok = c->d2h(out, c->out.p, total, "D2H output") &&
          c->check(hipStreamSynchronize(s), "sync");
     if (!ok) return SNP_ERR_DEVICE;
     *written = total;
@@ -810,7 +950,7 @@ snp_status snp_frame_decode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
     u32* d_out_len = d_out_cap + nc;
     i32* d_status = reinterpret_cast<i32*>(d_out_len + nc);
     u8* d_type = reinterpret_cast<u8*>(d_status + nc);
-    bool ok = c->check(hipMemcpyAsync(c->in.p, in, n, hipMemcpyHostToDevice, s), "H2D input");
+    bool ok = c->h2d(c->in.p, in, n, "H2D input");
     ok = ok && c->check(hipMemcpyAsync(d_body_off, cs.body_off.data(), nc * 8ull, hipMemcpyHostToDevice, s), "H2D meta");
     ok = ok && c->check(hipMemcpyAsync(d_out_off, cs.out_off.data(), nc * 8ull, hipMemcpyHostToDevice, s), "H2D meta");
     ok = ok && c->check(hipMemcpyAsync(d_body_len, cs.body_len.data(), nc * 4ull, hipMemcpyHostToDevice, s), "H2D meta");
@@ -830,7 +970,7 @@ snp_status snp_frame_decode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
         if (status[i] != SNP_OK) return static_cast<snp_status>(status[i]);   // as the sequential reference would throw
     if (cs.tail != SNP_OK) return cs.tail;
     if (cs.total) {
-        ok = c->check(hipMemcpyAsync(out, c->out.p, cs.total, hipMemcpyDeviceToHost, s), "D2H output") &&
+        ok = c->d2h(out, c->out.p, cs.total, "D2H output") &&
              c->check(hipStreamSynchronize(s), "sync");
         if (!ok) return SNP_ERR_DEVICE;
     }
