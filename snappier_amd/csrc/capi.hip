@@ -25,10 +25,12 @@ hipError_t snp_launch_compress(const u8*, const u64*, const u32*, u32, u8*, cons
                                hipStream_t);
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
                                    hipStream_t);
+hipError_t snp_launch_decompress_small(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*,
+                                       u32, hipStream_t);
 hipError_t snp_launch_decompress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*,
                                        const u8*, hipStream_t);
 hipError_t snp_launch_compress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, void*,
-                                     hipStream_t);
+                                     u32*, hipStream_t);
 size_t snp_compress_lanes_workspace(u32);
 hipError_t snp_probe_tables(void*, u32, hipStream_t, float*);
 hipError_t snp_launch_crc32c(const u8*, const u64*, const u32*, u32, int, u32*, const u32*, i32*, hipStream_t);
@@ -135,8 +137,13 @@ struct snp_ctx {
     int compress_mode = 0;   // 0 auto, 1 wave-per-fragment single-token rounds (compress.hip), 2 fragment-per-lane with HBM tables
                              // (compress_lanes.hip), 3 wave-per-fragment multi-token windows (compress_win.hip)
     int win_np = 1;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2; 2 measured slower)
+    u32 small_max = 512;     // blocks declaring at most this many bytes are decoded one per LANE (decompress_small.hip); 0 = never.
+                             // Measured (profiles/r02d_small_blocks.jsonl): the lane kernel runs at ~190 GB/s whatever the block size
+                             // (uncoalesced 16-byte accesses: the same transaction-rate wall as the lane compressor), the wave kernel at
+                             // 126 / 251 / 427 GB/s for 256 B / 1 KiB / 4 KiB blocks: the crossover is between 512 B and 1 KiB.
+    u32 small_min_blocks = 4096;   // ... in batches of at least this many blocks
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
-    DevBuf in, out, meta, work, tables, scan;
+    DevBuf in, out, meta, work, tables, scan, small;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
     uint64_t counters[4] = {0, 0, 0, 0};   // snp_ctx_counter
     std::string err;
@@ -149,8 +156,18 @@ struct snp_ctx {
         if (lanes)
             return check(snp_launch_decompress_lanes(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
                                                      chunk_type, stream), "decompress (lanes) launch");
+        // Large batches first go through the block-per-lane kernel, which finishes every clean block of <= small_max bytes
+        // and marks the rest; the wave kernel then takes exactly those (all of them when every block is a 64 KiB block: the
+        // first launch is then 163 840 lanes that read two words each).
+        int redo = 0;
+        if (small_max && nblocks >= small_min_blocks && decode_layout == 0) {
+            if (!check(snp_launch_decompress_small(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
+                                                   chunk_type, small_max, stream), "decompress (small blocks) launch"))
+                return false;
+            redo = 16;
+        }
         return check(snp_launch_decompress(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
-                                           chunk_type, fenced | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch");
+                                           chunk_type, fenced | redo | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch");
     }
 
     // One launch of the compressor over nblocks fragments, picking the layout (see compress_lanes.hip).
@@ -171,11 +188,12 @@ struct snp_ctx {
         // 64 KiB of table per fragment in flight: very large batches (millions of small blocks) go in slices, so the
         // workspace stays <= 16 GiB; 262 144 fragments per launch still fill the chip many times over
         constexpr u32 kSlice = 262144;
-        if (!ensure_tables(nblocks < kSlice ? nblocks : kSlice)) return false;
+        if (!ensure_tables(nblocks < kSlice ? nblocks : kSlice) || !ensure(small, 256, "hipMalloc(scalars)")) return false;
         for (u32 first = 0; first < nblocks; first += kSlice) {
             const u32 cnt = nblocks - first < kSlice ? nblocks - first : kSlice;
             if (!check(snp_launch_compress_lanes(d_in, in_off + first, in_len + first, cnt, d_out, out_off + first,
-                                                 out_len + first, status + first, variant, emit_varint, tables.p, stream),
+                                                 out_len + first, status + first, variant, emit_varint, tables.p,
+                                                 static_cast<u32*>(small.p), stream),
                        "compress (lanes) launch"))
                 return false;
         }
@@ -348,8 +366,10 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     }
     // debug knobs: SNAPPIER_HIP_FENCED=1 drains vmcnt before reading young output; SNAPPIER_HIP_DECODE=serial
     // disables the token-parallel front end of the decompressor (bit 1 of the kernel mode)
+    // FENCED (drain vmcnt before a wave reads output bytes it stored itself) is the default: measured 0.9 % slower than relying
+    // on in-order vector memory (17.22 vs 17.38 ms per 10 GiB, profiles/r02c_fenced_ab.jsonl); SNAPPIER_HIP_FENCED=0 turns it off
     const char* f = getenv("SNAPPIER_HIP_FENCED");
-    c->fenced = (f && f[0] == '1') ? 1 : 0;
+    c->fenced = (f && f[0] == '0') ? 0 : 1;
     const char* m = getenv("SNAPPIER_HIP_DECODE");
     if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
     if (m && strcmp(m, "batched") == 0) c->fenced |= 4;                 // token-parallel batches without the execution queue
@@ -364,6 +384,10 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     if (wn) c->win_np = atoi(wn) == 2 ? 2 : 1;
     const char* fs = getenv("SNAPPIER_HIP_FRAME_SCAN");
     c->frame_scan = (fs && strcmp(fs, "serial") == 0) ? 1 : 0;
+    const char* sm = getenv("SNAPPIER_HIP_SMALL_MAX");
+    if (sm) c->small_max = static_cast<u32>(strtoul(sm, nullptr, 10));
+    const char* sn = getenv("SNAPPIER_HIP_SMALL_MIN");
+    if (sn) c->small_min_blocks = static_cast<u32>(strtoul(sn, nullptr, 10));
     const char* wm = getenv("SNAPPIER_HIP_WIN_MAX");
     if (wm) c->win_max = static_cast<u32>(strtoul(wm, nullptr, 10));
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
@@ -384,7 +408,7 @@ void snp_ctx_destroy(snp_ctx* c)
     {
         DevGuard dg(c);
         (void)hipStreamSynchronize(c->stream);
-        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan})
+        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan, &c->small})
             if (b->p) (void)hipFree(b->p);
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);
         delete c->pool;

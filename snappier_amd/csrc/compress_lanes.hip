@@ -205,7 +205,8 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                                                             const u32* __restrict__ in_len, u32 nblocks,
                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
                                                             u32* __restrict__ out_len, i32* __restrict__ status,
-                                                            int emit_varint, u32* __restrict__ tables, int lit_blind)
+                                                            int emit_varint, u32* __restrict__ tables, int lit_blind,
+                                                            const u32* __restrict__ max_len)
 {
     __shared__ u16 lut[4][256];
     if (VARIANT == SNP_HASH_CRC32C) {
@@ -215,6 +216,20 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     }
     __shared__ u8 s_out[SNP_WAVE * kStageStride];
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    // Table stride = CalculateTableSize of the LONGEST fragment of the batch (HashTable.cs:57-71; k_max_len ran before this
+    // launch): a batch of 256-byte blocks keeps 1 KiB of table per fragment, not 64 KiB.  The wavefront's tables are one
+    // contiguous run, zeroed here with coalesced 16-byte stores (HashTable.cs:52) instead of a memset of the worst case.
+    const u32 maxlen = *max_len;
+    const u32 tstride = maxlen > 16384 ? 16384u : maxlen < 256 ? 256u : (2u << (31u - __clz(maxlen - 1)));
+    {
+        const u32 first = blockIdx.x * blockDim.x;
+        const u32 mine = nblocks - first < blockDim.x ? nblocks - first : blockDim.x;
+        u32* wt = tables + static_cast<size_t>(first) * tstride;
+        const size_t words = static_cast<size_t>(mine) * tstride;       // a multiple of 256
+        for (size_t i = static_cast<size_t>(threadIdx.x) * 4; i < words; i += static_cast<size_t>(blockDim.x) * 4)
+            *reinterpret_cast<uint4*>(wt + i) = make_uint4(0, 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // other lanes' stores, before this lane probes its table
+    }
     if (b >= nblocks) return;
     const bool staged = (lit_blind & 16) != 0;
     OutStage stg{s_out + threadIdx.x * kStageStride, 0};
@@ -223,7 +238,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     c.src = in + in_off[b];
     c.dst = out + out_off[b];
     c.n = in_len[b];
-    c.table = tables + static_cast<size_t>(b) * 16384u;
+    c.table = tables + static_cast<size_t>(b) * tstride;
     const u32 n = c.n;
     c.first4 = n >= 4 ? ld32u(c.src) : 0u;
     if (n > SNP_BLOCK_SIZE) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; return; }
@@ -567,13 +582,24 @@ extern "C" hipError_t snp_probe_tables(void* tables, u32 nblocks, hipStream_t st
 
 extern "C" size_t snp_compress_lanes_workspace(u32 nblocks) { return static_cast<size_t>(nblocks) * 16384u * sizeof(u32); }
 
+// longest fragment of the batch, on the device (the host never sees the lengths of a device-resident batch)
+__global__ __launch_bounds__(256) void k_max_len(const u32* __restrict__ in_len, u32 nblocks, u32* __restrict__ max_len)
+{
+    u32 m = 0;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < nblocks; i += gridDim.x * 256) m = max(m, in_len[i]);
+    for (int sh = 32; sh >= 1; sh >>= 1) m = max(m, static_cast<u32>(__shfl_xor(static_cast<int>(m), sh, 64)));
+    if ((threadIdx.x & 63u) == 0) atomicMax(max_len, m);
+}
+
 extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                                 const u64* out_off, u32* out_len, i32* status, int variant,
-                                                int emit_varint, void* tables, hipStream_t stream)
+                                                int emit_varint, void* tables, u32* max_len, hipStream_t stream)
 {
     if (nblocks == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(tables, 0, snp_compress_lanes_workspace(nblocks), stream);   // HashTable.cs:52
+    hipError_t e = hipMemsetAsync(max_len, 0, sizeof(u32), stream);
     if (e != hipSuccess) return e;
+    const u32 mgrid = (nblocks + 255) / 256 < 1024 ? (nblocks + 255) / 256 : 1024u;
+    hipLaunchKernelGGL(k_max_len, dim3(mgrid), dim3(256), 0, stream, in_len, nblocks, max_len);
     // Fragments per wavefront: 64 when there are enough fragments to fill the chip that way; fewer (partially filled
     // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
     const char* env = getenv("SNAPPIER_HIP_LANES_PER_WAVE");
@@ -595,7 +621,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const u32 slots = se ? static_cast<u32>(atoi(se)) : (nblocks >= 131072 ? kDefaultSlots : 2u);
 #define SNP_LAUNCH_CL(V, S)                                                                                          \
     hipLaunchKernelGGL((k_compress_lanes<V, S>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
-                       out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind)
+                       out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind, max_len)
     if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 1); else SNP_LAUNCH_CL(SNP_HASH_CRC32C, 2); }
     else { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_MUL, 1); else SNP_LAUNCH_CL(SNP_HASH_MUL, 2); }
 #undef SNP_LAUNCH_CL

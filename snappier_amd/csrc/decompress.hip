@@ -191,11 +191,12 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
                                                         const u64* __restrict__ out_off,
                                                         const u32* __restrict__ out_cap, u32* __restrict__ out_len,
                                                         i32* __restrict__ status, const u8* __restrict__ chunk_type,
-                                                        const u32* __restrict__ frag_skip)
+                                                        const u32* __restrict__ frag_skip, int redo_only)
 {
     static_assert(!FRAG || FRONT != 1, "fragment mode: serial loop or queued front end");
     const u32 b = blockIdx.x;
     if (b >= nblocks) return;
+    if (redo_only && status[b] != -1) return;            // decompress_small.hip finished this block (it marks the others -1)
     const u32 lane = lane_id();
     const u8* src = in + in_off[b];
     const u32 n = bcast_first(in_len[b]);
@@ -781,15 +782,15 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
                                             const u8* chunk_type, int mode, hipStream_t stream, const u32* frag_skip)
 {
     // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end), bit 2: batches without the execution queue;
-    // bits 8..: dynamic LDS bytes / 256 requested per wavefront purely to cap how many blocks a CU decodes at once
+    // bit 4: only the blocks decompress_small.hip left marked -1;  bits 8..: dynamic LDS bytes / 256 requested per wavefront purely to cap how many blocks a CU decodes at once
     if (nblocks == 0) return hipSuccess;
     const unsigned lds_bytes = static_cast<unsigned>(mode >> 8) * 256u;
 #define SNP_LAUNCH_DEC(F, B)                                                                                        \
     hipLaunchKernelGGL((k_decompress<F, B, false>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off,    \
-                       in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr)
+                       in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr, (mode >> 4) & 1)
 #define SNP_LAUNCH_FRAG(F, B)                                                                                       \
     hipLaunchKernelGGL((k_decompress<F, B, true>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off,     \
-                       in_len, nblocks, out, out_off, out_cap, out_len, status, nullptr, frag_skip)
+                       in_len, nblocks, out, out_off, out_cap, out_len, status, nullptr, frag_skip, 0)
     if (frag_skip) {                                    // fragments of one large block (tag_index.hip)
         switch (mode & 7) {
             case 0: case 4: SNP_LAUNCH_FRAG(false, 2); break;

@@ -133,9 +133,13 @@ def corrupt(rng: np.random.Generator, z: np.ndarray) -> np.ndarray:
     return z
 
 
-@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "lanes"])
+@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "lanes", "small"])
 def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatch):
-    monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
+    if decode == "small":       # every block first goes through the block-per-lane kernel (decompress_small.hip), whatever its size
+        monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
+        monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "65536")
+    else:
+        monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
     for r in range(ROUNDS):

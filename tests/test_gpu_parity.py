@@ -398,14 +398,18 @@ def test_compress_layouts_are_bit_identical(layout, monkeypatch):
                         O.compress(read_testdata(name), variant))
 
 
-@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "lanes"])
+@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "lanes", "small"])
 @pytest.mark.parametrize("fenced", ["0", "1"])
 def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     """Same-wave store->load ordering: the default kernel relies on in-order vector memory; the fenced variant drains
     vmcnt before touching young output.  The token-parallel front end and the serial loop must also agree.  All four
     kernel variants must be exact on the overlap-heavy config, the html-like config and the mixed corpus."""
     monkeypatch.setenv("SNAPPIER_HIP_FENCED", fenced)
-    monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
+    if decode == "small":       # block-per-lane kernel first, for every block size; what it cannot finish goes to the wave kernel
+        monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
+        monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "65536")
+    else:
+        monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
     nb = 512
     _roundtrip_blocks(cd, SD.low_entropy_blocks(1000, nb, "cuda"), nb, O.HASH_CRC32C, 128)
@@ -427,6 +431,46 @@ def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     _dlen, dst = cd.decompress(to_dev(data), to_dev(in_off), to_dev(in_len), out, to_dev(out_off), to_dev(out_cap))
     torch.cuda.synchronize()
     assert dst.cpu().tolist() == [O.decompress_status(b, c) for b, c in zip(blobs, caps)]
+
+
+@pytest.mark.parametrize("bs", [64, 256, 1000, 4096])
+def test_many_small_blocks_roundtrip_and_parity(bs):               # SURVEY 8(f4); SnappyStreamTests.cs:145-192 pattern
+    """Batches of small blocks take the block-per-lane decoder and the lane compressor with small tables: every block
+    round-trips, a sample equals the oracle byte for byte, and corrupted small blocks report the oracle's status."""
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    total = 8 << 20
+    nb = total // bs
+    raw = SD.corpus_blocks([read_testdata(n) for n in CORPUS], 3, total // 65536, SD.MIXED_SEED, "cuda")[: nb * bs]
+    in_off, in_len = cd.uniform_layout(nb, bs)
+    out, out_off, out_len, status = cd.compress(raw, in_off, in_len)
+    back = torch.zeros_like(raw)
+    dlen, dst = cd.decompress(out, out_off, out_len, back, in_off, in_len)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and bool((dlen == bs).all())
+    assert torch.equal(back, raw)
+    lens = out_len.cpu().numpy()
+    h_raw, h_out, h_off = raw.cpu().numpy(), out.cpu().numpy(), out_off.cpu().numpy()
+    for b in range(0, nb, max(1, nb // 200)):
+        assert h_out[h_off[b]: h_off[b] + lens[b]].tobytes() == O.compress(h_raw[b * bs:(b + 1) * bs].tobytes()), b
+    # corrupt one byte in every 7th block: status (and bytes when it still decodes) as the oracle
+    rng = np.random.default_rng(bs)
+    h_out = h_out.copy()
+    victims = list(range(1, nb, 7))[:4000]
+    for b in victims:
+        h_out[h_off[b] + int(rng.integers(0, lens[b]))] ^= int(rng.integers(1, 256))
+    back.zero_()
+    dlen, dst = cd.decompress(to_dev(h_out), out_off, out_len, back, in_off, in_len)
+    torch.cuda.synchronize()
+    dst, dlen, h_back = dst.cpu().numpy(), dlen.cpu().numpy(), back.cpu().numpy()
+    for b in victims[:600]:
+        blob = h_out[h_off[b]: h_off[b] + lens[b]].tobytes()
+        want = O.decompress_status(blob, bs)
+        assert dst[b] == want, (b, dst[b], want)
+        if want == 0:
+            assert h_back[b * bs: b * bs + dlen[b]].tobytes() == O.decompress(blob)
+    clean = np.ones(nb, dtype=bool)
+    clean[victims] = False
+    assert (dst[clean] == 0).all()
 
 
 # ------------------------------------------------------------------ CRC-32C
