@@ -26,6 +26,16 @@ EDGE_LENGTHS = [0, 1, 3, 4, 14, 15, 16, 17, 18, 19, 31, 32, 60, 61, 64, 65, 255,
                 32768, 65520, 65521, 65535, 65536]
 
 
+def log_session(**kw):
+    """One JSON line per fuzz session (what ran, with which seeds, how many blocks): gpurun_out/fuzz_log.jsonl; the long
+    session of scripts/fuzz_parity.sh is copied to profiles/ as the record of what was compared."""
+    import json
+    from conftest import ROOT
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "fuzz_log.jsonl"), "a") as f:
+        f.write(json.dumps(kw) + "\n")
+
+
 def make_block(rng: np.random.Generator, text: np.ndarray) -> np.ndarray:
     n = int(rng.choice(EDGE_LENGTHS)) if rng.integers(0, 3) == 0 else int(rng.integers(0, 65537))
     kind = int(rng.integers(0, 7))
@@ -105,6 +115,8 @@ def test_fuzz_compress_bytes_equal_oracle(layout, variant, monkeypatch):
             got = out[out_off[b]: out_off[b] + out_len[b]]
             want = ref[int(ref_off[b]): int(ref_off[b]) + int(ref_len[b])]
             assert np.array_equal(got, want), f"round {r} block {b} (len {lens[b]}) {layout} v{variant}"
+    log_session(test="compress_bytes_equal_oracle", layout=layout, hash_variant=variant, rounds=ROUNDS, blocks_per_round=BLOCKS,
+                blocks_compared=ROUNDS * BLOCKS, seeds=[1000 * r + 17 * variant + (layout == "lanes") for r in range(ROUNDS)], result="all equal")
 
 
 def corrupt(rng: np.random.Generator, z: np.ndarray) -> np.ndarray:
@@ -167,3 +179,5 @@ def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatc
         for b in ok:
             assert np.array_equal(out[out_off[b]: out_off[b] + dlen[b]], ref[out_off[b]: out_off[b] + ref_len[b]]), f"round {r} block {b}"
         assert ok.size > BLOCKS // 10 and ok.size < BLOCKS    # the corruptions produce both outcomes
+    log_session(test="corrupted_streams_status_and_bytes_equal_oracle", decode=decode, rounds=ROUNDS, blocks_per_round=BLOCKS,
+                blocks_compared=ROUNDS * BLOCKS, seeds=[777 + r for r in range(ROUNDS)], result="all statuses and bytes equal")
