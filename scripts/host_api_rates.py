@@ -2,7 +2,7 @@
 """Throughput of the HOST-pointer boundary (snp_try_compress / snp_try_decompress / snp_frame_encode / snp_frame_decode),
 called through ctypes on preallocated pageable numpy buffers exactly as a P/Invoke caller would: the PCIe transfers are
 inside the timed call.  These are the numbers DESIGN.md quotes as "PCIe-inclusive"; they are never bench.py's `value`.
-One JSON line per size.  SNAPPIER_HIP_PINNED=1 selects the library's own pinned-slice pipeline for comparison."""
+One JSON line per size."""
 import ctypes as C, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -43,7 +43,7 @@ for n in sizes:
     t_fe, wf = best(lambda: call(L.snp_frame_encode, data, n, framed), 2)
     t_fd, wb = best(lambda: call(L.snp_frame_decode, framed, wf, back), 2)
     assert wb == n and np.array_equal(back, data)
-    print(json.dumps({"bytes": n, "ratio": round(wc / n, 4), "pinned_pipeline": os.environ.get("SNAPPIER_HIP_PINNED", "0") == "1",
+    print(json.dumps({"bytes": n, "ratio": round(wc / n, 4), 
                       "compress_ms": round(t_c * 1e3, 3), "compress_GBps": round(n / t_c / 1e9, 3),
                       "decompress_ms": round(t_d * 1e3, 3), "decompress_GBps": round(n / t_d / 1e9, 3),
                       "frame_encode_GBps": round(n / t_fe / 1e9, 3), "frame_decode_GBps": round(n / t_fd / 1e9, 3)}), flush=True)

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 html = open("tests/golden/testdata/html", "rb").read()
 res = {}
-for layout in ("wave", "lanes64", "lanes32", "lanes16", "lanes8"):
+for layout in ("win", "lanes64", "lanes32", "lanes16", "lanes8"):
     os.environ["SNAPPIER_HIP_COMPRESS"] = layout[:5] if layout.startswith("lanes") else layout
     if layout.startswith("lanes"):
         os.environ["SNAPPIER_HIP_LANES_PER_WAVE"] = layout[5:]

@@ -1,17 +1,14 @@
 // capi.hip -- the C-ABI of libsnappier_hip.so (include/snappier_hip.h): contexts, HBM scratch, host staging and
 // the launch sequences behind each entry point.  No codec arithmetic happens on the host: every byte of compress /
-// decompress / CRC work is done by the gfx950 kernels in compress.hip, decompress.hip, crc32c.hip, framing.hip.
+// decompress / CRC work is done by the gfx950 kernels in compress_lanes.hip, compress_win.hip, decompress.hip,
+// decompress_small.hip, tag_index.hip, crc32c.hip, framing.hip, frame_scan.hip.
 // There is no CPU fallback -- without a HIP device snp_ctx_create fails with SNP_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
-#include <condition_variable>
 #include <cstdio>
 #include <cstring>
-#include <functional>
-#include <mutex>
 #include <new>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "snp_device.h"
@@ -21,14 +18,10 @@ hipError_t snp_launch_decompress(const u8*, const u64*, const u32*, u32, u8*, co
                                  const u8*, int, hipStream_t, const u32*);
 u32 snp_tag_index_entries(u32, u32);
 hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
-hipError_t snp_launch_compress(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int,
-                               hipStream_t);
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
                                    hipStream_t);
 hipError_t snp_launch_decompress_small(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*,
                                        u32, hipStream_t);
-hipError_t snp_launch_decompress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*,
-                                       const u8*, hipStream_t);
 hipError_t snp_launch_compress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, void*,
                                      u32*, hipStream_t);
 size_t snp_compress_lanes_workspace(u32);
@@ -60,70 +53,6 @@ inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
-// ---- host <-> device transfers of the host-pointer entry points --------------------------------------------------
-// The reference's Span API hands over pageable memory.  Optional path (SNAPPIER_HIP_PINNED=1): three context-owned PINNED
-// slices, DMA of slice i+1, i+2 in flight while worker threads memcpy slice i between the pinned slice and the caller's
-// buffer.  Default is the runtime's own pageable hipMemcpy, which measured faster (see ensure_pipe).
-class CopyPool {
-public:
-    explicit CopyPool(unsigned nthreads)
-    {
-        for (unsigned t = 0; t < nthreads; ++t) workers_.emplace_back([this] { run(); });
-    }
-    ~CopyPool()
-    {
-        { std::lock_guard<std::mutex> g(m_); quit_ = true; }
-        cv_.notify_all();
-        for (auto& w : workers_) w.join();
-    }
-    // memcpy split over the workers (and the caller); returns when every byte is copied
-    void copy(void* dst, const void* src, size_t n)
-    {
-        const size_t parts = workers_.size() + 1;
-        const size_t piece = ((n + parts - 1) / parts + 4095) & ~static_cast<size_t>(4095);
-        if (n < (1u << 20) || workers_.empty()) { memcpy(dst, src, n); return; }
-        size_t mine_off = 0, mine_len = piece < n ? piece : n;
-        {
-            std::lock_guard<std::mutex> g(m_);
-            for (size_t off = piece; off < n; off += piece) {
-                jobs_.push_back({static_cast<u8*>(dst) + off, static_cast<const u8*>(src) + off, off + piece < n ? piece : n - off});
-                ++pending_;
-            }
-        }
-        cv_.notify_all();
-        memcpy(static_cast<u8*>(dst) + mine_off, static_cast<const u8*>(src) + mine_off, mine_len);
-        std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return pending_ == 0; });
-    }
-
-private:
-    struct Job { u8* d; const u8* s; size_t n; };
-    void run()
-    {
-        for (;;) {
-            Job j;
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [this] { return quit_ || !jobs_.empty(); });
-                if (quit_ && jobs_.empty()) return;
-                j = jobs_.back();
-                jobs_.pop_back();
-            }
-            memcpy(j.d, j.s, j.n);
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (--pending_ == 0) done_.notify_all();
-            }
-        }
-    }
-    std::vector<std::thread> workers_;
-    std::vector<Job> jobs_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    size_t pending_ = 0;
-    bool quit_ = false;
-};
-
 struct snp_ctx {
     int device = 0;
     int variant = SNP_HASH_CRC32C;
@@ -131,11 +60,11 @@ struct snp_ctx {
     bool own_stream = false;
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
     int dec_lds = 0;         // dynamic LDS bytes per decode wavefront (occupancy throttle)
-    int decode_layout = 0;   // 0/1 wave-per-block (default), 2 block-per-lane (SNAPPIER_HIP_DECODE=lanes)
+    int decode_layout = 0;   // 0 default (small blocks one per lane, the rest one per wavefront), 1 a debug front end is pinned
     int table_tries = 6;     // candidates tried when a >= 1 GiB hash-table workspace is allocated (SNAPPIER_HIP_TABLE_TRIES)
     u32 par_min = 4 * SNP_BLOCK_SIZE;   // single blocks at least this long are decoded one wavefront per 64 KiB fragment (0 = never)
-    int compress_mode = 0;   // 0 auto, 1 wave-per-fragment single-token rounds (compress.hip), 2 fragment-per-lane with HBM tables
-                             // (compress_lanes.hip), 3 wave-per-fragment multi-token windows (compress_win.hip)
+    int compress_mode = 0;   // 0 auto by batch size, 2 fragment-per-lane with HBM tables (compress_lanes.hip), 3 fragment-per-wavefront
+                             // with the table in LDS, multi-token windows (compress_win.hip)
     int win_np = 1;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2; 2 measured slower)
     u32 small_max = 512;     // blocks declaring at most this many bytes are decoded one per LANE (decompress_small.hip); 0 = never.
                              // Measured (profiles/r02d_small_blocks.jsonl): the lane kernel runs at ~190 GB/s whatever the block size
@@ -148,14 +77,10 @@ struct snp_ctx {
     uint64_t counters[4] = {0, 0, 0, 0};   // snp_ctx_counter
     std::string err;
 
-    // One launch of the decompressor over nblocks blocks, picking the layout (see decompress_lanes.hip).
+    // One launch sequence of the decompressor over nblocks blocks (decompress_small.hip, then decompress.hip).
     bool launch_decompress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
                            const u32* out_cap, u32* out_len, i32* status, const u8* chunk_type)
     {
-        const bool lanes = decode_layout == 2;   // measured slower than the wave kernel at every batch size: opt-in only
-        if (lanes)
-            return check(snp_launch_decompress_lanes(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
-                                                     chunk_type, stream), "decompress (lanes) launch");
         // Large batches first go through the block-per-lane kernel, which finishes every clean block of <= small_max bytes
         // and marks the rest; the wave kernel then takes exactly those (all of them when every block is a 64 KiB block: the
         // first launch is then 163 840 lanes that read two words each).
@@ -181,10 +106,6 @@ struct snp_ctx {
         if (win)
             return check(snp_launch_compress_win(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
                                                  emit_varint, win_np, stream), "compress (windows) launch");
-        const bool lanes = compress_mode == 2 || compress_mode == 0;
-        if (!lanes)
-            return check(snp_launch_compress(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
-                                             emit_varint, stream), "compress launch");
         // 64 KiB of table per fragment in flight: very large batches (millions of small blocks) go in slices, so the
         // workspace stays <= 16 GiB; 262 144 fragments per launch still fill the chip many times over
         constexpr u32 kSlice = 262144;
@@ -217,71 +138,16 @@ struct snp_ctx {
         b.cap = want;
         return true;
     }
-    // ---- pipelined transfers (see CopyPool) -------------------------------------------------------------------------
-    static constexpr size_t kSlice = 32u << 20;      // bytes per pinned slice
-    static constexpr size_t kPipeMin = 8u << 20;     // smaller transfers go straight through hipMemcpyAsync
-    void* pin[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t pin_ev[3] = {nullptr, nullptr, nullptr};
-    CopyPool* pool = nullptr;
-    int pipe_state = 0;                              // 0 untried, 1 ready, -1 unavailable (plain copies)
-    bool ensure_pipe()
-    {
-        if (pipe_state) return pipe_state > 0;
-        // Measured on the MI355X box (profiles/r02b_host_api_rates.jsonl): the runtime's own pageable path already moves
-        // 1 GiB at ~40 GB/s, FASTER than this pipeline (31 GB/s: the worker memcpys are the slow leg).  So it is opt-in.
-        const char* on = getenv("SNAPPIER_HIP_PINNED");
-        pipe_state = -1;
-        if (!on || on[0] != '1') return false;
-        for (int k = 0; k < 3; ++k) {
-            if (hipHostMalloc(&pin[k], kSlice, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pin[k] = nullptr; return false; }
-            if (hipEventCreateWithFlags(&pin_ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
-        }
-        unsigned hw = std::thread::hardware_concurrency();
-        const char* th = getenv("SNAPPIER_HIP_COPY_THREADS");
-        unsigned nt = th ? static_cast<unsigned>(atoi(th)) : (hw >= 32 ? 7u : hw >= 8 ? 3u : 1u);
-        pool = new (std::nothrow) CopyPool(nt > 31 ? 31 : nt);
-        if (!pool) return false;
-        pipe_state = 1;
-        return true;
-    }
-    // host -> device, n bytes; on return the caller's buffer has been read completely (copies may still be in flight on `stream`)
+    // Host <-> device transfers of the host-pointer entry points: the caller's buffers are pageable (the reference's Span API)
+    // and the runtime's own pageable path moves them at ~40 GB/s; a pinned-slice pipeline inside the library measured slower
+    // (31 GB/s, profiles/r02b_host_api_rates.jsonl) and was removed.
     bool h2d(void* dev, const void* host, size_t n, const char* what)
     {
-        if (n < kPipeMin || !ensure_pipe()) return check(hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, stream), what);
-        size_t i = 0;
-        for (size_t off = 0; off < n; off += kSlice, ++i) {
-            const size_t len = n - off < kSlice ? n - off : kSlice;
-            const int b = static_cast<int>(i % 3);
-            if (i >= 3 && !check(hipEventSynchronize(pin_ev[b]), what)) return false;      // the DMA that last read this slice
-            pool->copy(pin[b], static_cast<const u8*>(host) + off, len);
-            if (!check(hipMemcpyAsync(static_cast<u8*>(dev) + off, pin[b], len, hipMemcpyHostToDevice, stream), what)) return false;
-            if (!check(hipEventRecord(pin_ev[b], stream), what)) return false;
-        }
-        // later users of the slices (another h2d/d2h) must not overwrite them before these DMAs have read them
-        return check(hipStreamSynchronize(stream), what);
+        return check(hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, stream), what);
     }
-    // device -> host, n bytes, ordered after everything queued on `stream`; returns when the bytes are in the caller's buffer
     bool d2h(void* host, const void* dev, size_t n, const char* what)
     {
-        if (n < kPipeMin || !ensure_pipe())
-            return check(hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, stream), what) && check(hipStreamSynchronize(stream), what);
-        const size_t slices = (n + kSlice - 1) / kSlice;
-        auto issue = [&](size_t i) {
-            const size_t off = i * kSlice, len = n - off < kSlice ? n - off : kSlice;
-            const int b = static_cast<int>(i % 3);
-            return check(hipMemcpyAsync(pin[b], static_cast<const u8*>(dev) + off, len, hipMemcpyDeviceToHost, stream), what) &&
-                   check(hipEventRecord(pin_ev[b], stream), what);
-        };
-        for (size_t i = 0; i < slices && i < 2; ++i)
-            if (!issue(i)) return false;
-        for (size_t j = 0; j < slices; ++j) {
-            const size_t off = j * kSlice, len = n - off < kSlice ? n - off : kSlice;
-            const int b = static_cast<int>(j % 3);
-            if (!check(hipEventSynchronize(pin_ev[b]), what)) return false;
-            if (j + 2 < slices && !issue(j + 2)) return false;                              // slice (j+2)%3 was drained at step j-1
-            pool->copy(static_cast<u8*>(host) + off, pin[b], len);
-        }
-        return true;
+        return check(hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, stream), what) && check(hipStreamSynchronize(stream), what);
     }
 
     // The hash-table workspace of the lane compressor.  Large ones are placement-sensitive (compress_lanes.hip,
@@ -373,13 +239,13 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     const char* m = getenv("SNAPPIER_HIP_DECODE");
     if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
     if (m && strcmp(m, "batched") == 0) c->fenced |= 4;                 // token-parallel batches without the execution queue
-    c->decode_layout = (m && strcmp(m, "lanes") == 0) ? 2 : (m && (strcmp(m, "serial") == 0 || strcmp(m, "batched") == 0)) ? 1 : 0;
+    c->decode_layout = (m && (strcmp(m, "serial") == 0 || strcmp(m, "batched") == 0)) ? 1 : 0;
     // SNAPPIER_HIP_DEC_LDS=<bytes>: dynamic LDS per decode wavefront, an occupancy throttle (160 KiB / bytes blocks per CU)
     const char* dl = getenv("SNAPPIER_HIP_DEC_LDS");
     c->dec_lds = dl ? (atoi(dl) / 256) * 256 : kDefaultDecLds;
-    // SNAPPIER_HIP_COMPRESS=wave|lanes pins the compressor layout (default: by batch size)
+    // SNAPPIER_HIP_COMPRESS=win|lanes pins the compressor layout (default: by batch size)
     const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
-    c->compress_mode = (cm && strcmp(cm, "wave") == 0) ? 1 : (cm && strcmp(cm, "lanes") == 0) ? 2 : (cm && strncmp(cm, "win", 3) == 0) ? 3 : 0;
+    c->compress_mode = (cm && strcmp(cm, "lanes") == 0) ? 2 : (cm && strncmp(cm, "win", 3) == 0) ? 3 : 0;
     const char* wn = getenv("SNAPPIER_HIP_WIN_NP");
     if (wn) c->win_np = atoi(wn) == 2 ? 2 : 1;
     const char* fs = getenv("SNAPPIER_HIP_FRAME_SCAN");
@@ -411,11 +277,6 @@ void snp_ctx_destroy(snp_ctx* c)
         for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan, &c->small})
             if (b->p) (void)hipFree(b->p);
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);
-        delete c->pool;
-        for (int k = 0; k < 3; ++k) {
-            if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]);
-            if (c->pin[k]) (void)hipHostFree(c->pin[k]);
-        }
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -770,7 +631,7 @@ snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* 
             hb = i + 1;
             if (ch < 128) { clean = true; break; }
         }
-        if (ok && clean && c->par_min && expected >= c->par_min && expected <= cap32 && n > hb && c->decode_layout != 2) {
+        if (ok && clean && c->par_min && expected >= c->par_min && expected <= cap32 && n > hb) {
             const u32 nent = snp_tag_index_entries(static_cast<u32>(n), hb);
             const u32 nf = (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
             // fragment table: in_off, out_off (u64) ; in_len, out_cap, skip, out_len (u32) ; status (i32)

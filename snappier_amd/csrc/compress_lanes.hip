@@ -2,16 +2,17 @@
 // SnappyCompressor.CompressFragment (Snappier/Internal/SnappyCompressor.cs:174-415) for both TableEntry hashes.
 //
 // Why a second layout.  The reference parse is a serial chain: probe -> table lookup -> candidate compare -> insert,
-// ~14 000 table accesses per html-like fragment.  The wave-per-fragment kernel (compress.hip) keeps the table in LDS,
-// which caps a CU at 5 fragments in flight (5 x 32 KiB = all 160 KiB of LDS), and a lone wavefront is bound by
-// instruction issue (~300 instructions per round).  For LARGE batches the parallelism that matters is across
+// ~14 000 table accesses per html-like fragment.  The wave-per-fragment kernel (compress_win.hip) keeps the table in LDS,
+// which caps a CU at 4-5 fragments in flight (32 KiB each of 160 KiB of LDS), and a lone wavefront is bound by
+// instruction issue (one instruction per ~6 cycles).  For LARGE batches the parallelism that matters is across
 // fragments, so here every lane runs the serial parse of its own fragment: 64 fragments per wavefront, 163 840
-// independent memory streams in flight.  The 16384-entry hash table of each fragment lives in an HBM workspace (u32
-// entries: position + 16 check bits, 64 KiB per fragment, zeroed by a memset before the launch -- HashTable.cs:52);
+// independent memory streams in flight.  The hash table of each fragment lives in an HBM workspace (u32 entries: position +
+// 16 check bits; stride = CalculateTableSize of the batch's longest fragment, 64 KiB at 64 KiB; zeroed by the owning
+// wavefront at kernel start -- HashTable.cs:52,57-71);
 // LDS holds only the 4 x 256-entry table for the SNP_HASH_CRC32C hash (the CRC step is GF(2)-linear, so it factors
 // over the four input bytes; gfx950 has no CRC instruction).  The kernel is bound by the rate at which HBM serves
 // random 4-byte read-modify-writes to the tables (scripts/microbench_random_table.hip), not by
-// instruction issue.  Small batches keep using compress.hip (one wavefront per fragment is better there).
+// instruction issue.  Batches below 16 384 fragments use compress_win.hip (one wavefront per fragment is better there).
 #include <cstdlib>
 
 #include "snp_device.h"

@@ -59,8 +59,7 @@ def ctx(request, monkeypatch):
     par_min = {"default": 262144, "min1": 1, "off": 0}[request.param]
     monkeypatch.setenv("SNAPPIER_HIP_PARALLEL_MIN", str(par_min))       # explicit, whatever the caller's environment says
     c = S.Context(0, O.HASH_CRC32C)
-    # the block-per-lane decoder (SNAPPIER_HIP_DECODE=lanes) never takes the fragment path
-    c.par_min = 0 if __import__("os").environ.get("SNAPPIER_HIP_DECODE") == "lanes" else par_min
+    c.par_min = par_min
     return c
 
 

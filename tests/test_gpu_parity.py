@@ -361,9 +361,9 @@ def test_decompress_batch_per_block_status(codec):
     assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
 
 
-@pytest.mark.parametrize("layout", ["win", "win-np2", "wave", "wave-staged", "wave-unstaged", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31"])
+@pytest.mark.parametrize("layout", ["win", "win-np2", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31"])
 def test_compress_layouts_are_bit_identical(layout, monkeypatch):
-    """Both compressor layouts (one fragment per wavefront with the table in LDS; one fragment per lane with the table
+    """Both compressor layouts (one fragment per wavefront with the table in LDS -- the window kernel; one fragment per lane with the table
     in an HBM workspace) must give the oracle's bytes on every kind of input, ragged lengths included."""
     monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout.split("-")[0])
     if layout == "win-np2":             # window compressor with two positions per lane (default one)
@@ -372,8 +372,6 @@ def test_compress_layouts_are_bit_identical(layout, monkeypatch):
         monkeypatch.setenv("SNAPPIER_HIP_EXACT_LITERALS", "1")
     if "-opts" in layout:               # lane kernel with another set of output-store options (default 23; 7 = no LDS staging)
         monkeypatch.setenv("SNAPPIER_HIP_CL_OPTS", layout.split("-opts")[1])
-    if layout.endswith("staged"):       # wave kernel with / without the fragment staged in LDS (default: by batch size)
-        monkeypatch.setenv("SNAPPIER_HIP_STAGED", "1" if layout == "wave-staged" else "0")
     html = read_testdata("html")
     for variant in VARIANTS:
         cd = SB.BlockCodec(0, variant)
@@ -398,7 +396,7 @@ def test_compress_layouts_are_bit_identical(layout, monkeypatch):
                         O.compress(read_testdata(name), variant))
 
 
-@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "lanes", "small"])
+@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "small"])
 @pytest.mark.parametrize("fenced", ["0", "1"])
 def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     """Same-wave store->load ordering: the default kernel relies on in-order vector memory; the fenced variant drains
