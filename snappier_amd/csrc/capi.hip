@@ -195,6 +195,44 @@ struct snp_ctx {
                check(hipStreamWaitEvent(next, order_ev, 0), "hipStreamWaitEvent");
     }
     hipEvent_t order_ev = nullptr;
+    // Host input of nf 64 KiB fragments -> this->in, compressed into d_out.  Large inputs go up in slices on a copy stream and
+    // slice i is compressed while slice i+1 crosses PCIe (the fragments are independent; one launch per slice, small enough
+    // for the LDS-table kernel).  1 GiB: 57 -> 44 ms (profiles/r02i_host_api_rates.jsonl).
+    bool upload_and_compress(const u8* host_in, size_t n, u32 nf, const u64* d_in_off, const u32* d_in_len, u8* d_out,
+                             const u64* d_out_off, u32* d_out_len, i32* d_status, int emit_varint)
+    {
+        if (nf < 4096 || !copy_stream_ready())
+            return h2d(in.p, host_in, n, "H2D input") &&
+                   launch_compress(static_cast<const u8*>(in.p), d_in_off, d_in_len, nf, d_out, d_out_off, d_out_len, d_status, emit_varint);
+        const u32 per = nf >= 16384 ? 4096u : (nf + 3) / 4;
+        bool ok = true;
+        u32 k = 0;
+        for (u32 first = 0; first < nf && ok; first += per, ++k) {
+            const u32 cnt = nf - first < per ? nf - first : per;
+            const size_t off = static_cast<size_t>(first) * SNP_BLOCK_SIZE;
+            const size_t len = n - off < static_cast<size_t>(cnt) * SNP_BLOCK_SIZE ? n - off : static_cast<size_t>(cnt) * SNP_BLOCK_SIZE;
+            hipEvent_t ev = copy_ev[k & 1];
+            ok = check(hipMemcpyAsync(static_cast<u8*>(in.p) + off, host_in + off, len, hipMemcpyHostToDevice, copy_stream), "H2D input") &&
+                 check(hipEventRecord(ev, copy_stream), "event") && check(hipStreamWaitEvent(stream, ev, 0), "wait") &&
+                 launch_compress(static_cast<const u8*>(in.p), d_in_off + first, d_in_len + first, cnt, d_out, d_out_off + first,
+                                 d_out_len + first, d_status + first, emit_varint);
+        }
+        return ok;
+    }
+    // copy stream: host -> device slices that overlap the kernels of the previous slice
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    int copy_state = 0;
+    bool copy_stream_ready()
+    {
+        if (copy_state) return copy_state > 0;
+        copy_state = -1;
+        if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); copy_stream = nullptr; return false; }
+        for (auto& e : copy_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        copy_state = 1;
+        return true;
+    }
 };
 
 // Entry points run on the context's device and leave the caller's current device as they found it.
@@ -277,6 +315,8 @@ void snp_ctx_destroy(snp_ctx* c)
         for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan, &c->small})
             if (b->p) (void)hipFree(b->p);
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+        if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+        for (auto& e : c->copy_ev) if (e) (void)hipEventDestroy(e);
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -448,13 +488,10 @@ static FrameWork frame_work_layout(void* base, u64 n)
 
 uint64_t snp_frame_encode_workspace(uint64_t n) { return frame_work_layout(nullptr, n).bytes; }
 
-snp_status snp_frame_encode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap,
-                                   uint64_t* d_written, void* d_work)
+// host_in != nullptr: the raw stream is still in host memory; it is uploaded into d_in in slices that overlap the compressor
+static snp_status frame_encode_impl(snp_ctx* c, const uint8_t* d_in, const uint8_t* host_in, uint64_t n, uint8_t* d_out,
+                                    uint64_t cap, uint64_t* d_written, void* d_work)
 {
-    if (!c || !d_out || !d_written || !d_work || (n && !d_in)) return SNP_ERR_BAD_ARG;
-    if (n > 0xffffffffull * SNP_BLOCK_SIZE) return SNP_ERR_BAD_ARG;
-    DevGuard dg(c);
-    if (!dg.ok) return SNP_ERR_DEVICE;
     if (cap < SNP_STREAM_HEADER_LEN) return SNP_ERR_OUTPUT_TOO_SMALL;
     const u32 nc = static_cast<u32>((n + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE);
     hipStream_t s = c->stream;
@@ -463,7 +500,8 @@ snp_status snp_frame_encode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, 
     const FrameWork w = frame_work_layout(d_work, n);
     bool ok = c->check(snp_launch_frame_chunks(n, nc, kCompStride, w.in_off, w.in_len, w.comp_off, s), "frame chunks");
     // CompressBlock: TryCompress(chunk) = varint + one fragment  (SnappyStreamCompressor.cs:206)
-    ok = ok && c->launch_compress(d_in, w.in_off, w.in_len, nc, w.comp, w.comp_off, w.comp_len, w.status, 1);
+    if (host_in) ok = ok && c->upload_and_compress(host_in, n, nc, w.in_off, w.in_len, w.comp, w.comp_off, w.comp_len, w.status, 1);
+    else ok = ok && c->launch_compress(d_in, w.in_off, w.in_len, nc, w.comp, w.comp_off, w.comp_len, w.status, 1);
     // masked CRC-32C of the RAW chunk  (:243-245,258-260)
     ok = ok && c->check(snp_launch_crc32c(d_in, w.in_off, w.in_len, nc, 1, w.crc, nullptr, nullptr, s), "frame crc");
     ok = ok && c->check(snp_launch_frame_plan(w.in_len, w.comp_len, nc, w.type, w.payload, w.dst_off, d_written, s),
@@ -471,6 +509,16 @@ snp_status snp_frame_encode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, 
     ok = ok && c->check(snp_launch_frame_emit(d_in, w.in_off, w.comp, w.comp_off, w.type, w.payload, w.crc, w.dst_off,
                                               d_out, cap, nc, s), "frame emit");
     return ok ? SNP_OK : SNP_ERR_DEVICE;
+}
+
+snp_status snp_frame_encode_device(snp_ctx* c, const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap,
+                                   uint64_t* d_written, void* d_work)
+{
+    if (!c || !d_out || !d_written || !d_work || (n && !d_in)) return SNP_ERR_BAD_ARG;
+    if (n > 0xffffffffull * SNP_BLOCK_SIZE) return SNP_ERR_BAD_ARG;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
+    return frame_encode_impl(c, d_in, nullptr, n, d_out, cap, d_written, d_work);
 }
 
 snp_status snp_frame_decode_chunks_device(snp_ctx* c, const uint8_t* d_in, const uint8_t* chunk_type,
@@ -575,10 +623,8 @@ snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
     u32* d_comp_len = d_in_len + nf;
     i32* d_status = reinterpret_cast<i32*>(d_comp_len + nf);
 
-    bool ok = c->h2d(c->in.p, in, n, "H2D input");
-    ok = ok && c->check(snp_launch_frame_chunks(n, nf, kCompStride, d_in_off, d_in_len, d_comp_off, s), "fragment table");
-    ok = ok && c->launch_compress(static_cast<const u8*>(c->in.p), d_in_off, d_in_len, nf, static_cast<u8*>(c->work.p),
-                                  d_comp_off, d_comp_len, d_status, 0);
+    bool ok = c->check(snp_launch_frame_chunks(n, nf, kCompStride, d_in_off, d_in_len, d_comp_off, s), "fragment table");
+    ok = ok && c->upload_and_compress(in, n, nf, d_in_off, d_in_len, static_cast<u8*>(c->work.p), d_comp_off, d_comp_len, d_status, 0);
     std::vector<u32> comp_len(nf);
     ok = ok && c->check(hipMemcpyAsync(comp_len.data(), d_comp_len, nf * 4ull, hipMemcpyDeviceToHost, s), "D2H lengths");
     ok = ok && c->check(hipStreamSynchronize(s), "sync");
@@ -738,10 +784,9 @@ snp_status snp_frame_encode(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
         !c->ensure(c->work, wbytes + 16, "hipMalloc(work)") || !c->ensure(c->meta, 64, "hipMalloc(meta)"))
         return SNP_ERR_DEVICE;
     bool ok = true;
-    if (n) ok = c->h2d(c->in.p, in, n, "H2D input");
-    if (!ok) return SNP_ERR_DEVICE;
-    snp_status st = snp_frame_encode_device(c, static_cast<const u8*>(c->in.p), n, static_cast<u8*>(c->out.p), max_out,
-                                            static_cast<u64*>(c->meta.p), c->work.p);
+    if (n > 0xffffffffull * SNP_BLOCK_SIZE) return SNP_ERR_BAD_ARG;
+    snp_status st = frame_encode_impl(c, static_cast<const u8*>(c->in.p), n ? in : nullptr, n, static_cast<u8*>(c->out.p), max_out,
+                                      static_cast<u64*>(c->meta.p), c->work.p);
     if (st != SNP_OK) return st;
     u64 total = 0;
     ok = c->check(hipMemcpyAsync(&total, c->meta.p, 8, hipMemcpyDeviceToHost, s), "D2H total") &&
