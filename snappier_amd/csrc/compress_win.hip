@@ -18,7 +18,7 @@
 // positions the serial parse writes to the table (probes and ip-1 inserts).  The speculation was exact iff those
 // positions have pairwise distinct buckets: they publish to the table and read back; on a repeat the round is cut at
 // the first position whose bucket an earlier one of the round already used (min-position-wins publish makes every
-// later duplicate read a smaller position), the table is rolled back and the prefix re-walked.
+// later duplicate read a smaller position), the table is rolled back and the prefix below the cut is kept.
 // SPARSE round (scan beyond its 33rd probe -- incompressible data -- and the fragment tail): lane j speculates probe
 // slot j of the current scan (offsets D[], the skip heuristic's sequence), at most one token per round.
 // Tokens (position, length, offset) queue in LDS and are turned into literal/copy tags 64 at a time, one per lane
@@ -614,13 +614,32 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                         const u64 los = ballot64(pub[k] && rb[k] < pp[k]);
                         if (los) q2 = 64u * k + static_cast<u32>(__builtin_ctzll(los));
                     }
-                    // roll the table back, re-walk the prefix, publish it (distinct buckets by minimality of q2)
+                    // roll the table back and keep the prefix below q2 (distinct buckets by minimality of q2).  No second walk: the
+                    // events before q2 are those of the first one, and the state at q2 follows from the last token before it
+                    // (tests/window_model.c checks this against a re-walk).
                     lds_fence();
 #pragma unroll
                     for (int k = 0; k < NP; ++k)
                         if (pub[k]) table[h[k]] = static_cast<u16>(c[k]);
                     lds_fence();
-                    walk(q2);
+                    u32 last = kNone;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const u64 below = q2 >= 64u * (k + 1) ? ~0ull : q2 <= 64u * k ? 0ull : ((1ull << (q2 - 64u * k)) - 1ull);
+                        PUB[k] &= below;
+                        TOKM[k] &= below;
+                        if (TOKM[k]) last = 64u * k + 63u - static_cast<u32>(__builtin_clzll(TOKM[k]));
+                    }
+                    e = st;
+                    e.pend = false;
+                    if (last == kNone) e.pos = w + q2;
+                    else {
+                        const u32 ip = last + read_half<NP>(m, last);
+                        e.S = w + ip + 1;
+                        if (q2 + 1 == ip) { e.pos = w + ip; e.pend = true; }   // q2 is that copy's ip-1 insert: still pending
+                        else e.pos = w + q2;
+                    }
+                    e.kb = e.pos >= e.S ? e.pos - e.S : 0u;
                     xn_base = kNone;                                    // the prefetched window started somewhere else
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {

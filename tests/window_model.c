@@ -198,8 +198,24 @@ size_t wm_compress_fragment(const uint8_t* in, uint32_t n, uint8_t* out, int var
                 }
                 if (q2 < cut0) {
                     if (s) s->cuts++;
+                    /* The kernel does not walk again: the events before q2 are those of the first walk, and the state at q2
+                     * follows from the last token before it.  Both are computed here and must agree. */
+                    pstate quick = st;
+                    quick.pend = 0;
+                    int last = -1;
+                    for (int i = 0; i < nt; ++i)
+                        if (tok[i].t - w < q2) last = i;
+                    if (last < 0) { quick.pos = w + q2; }
+                    else {
+                        const uint32_t ip = tok[last].t + tok[last].len;          /* absolute */
+                        quick.S = ip + 1;
+                        if (w + q2 == ip - 1) { quick.pos = ip; quick.pend = 1; }   /* q2 is that copy's ip-1 insert: still pending */
+                        else quick.pos = w + q2;
+                    }
+                    quick.kb = quick.pos >= quick.S ? quick.pos - quick.S : 0;
                     trial = st;
                     nt = walk(in, n, limit, w, q2, hit, cand, mlen, resolved, &trial, visited, tok, NULL);
+                    if (quick.S != trial.S || quick.pos != trial.pos || quick.pend != trial.pend || quick.kb != trial.kb || trial.done || nt != last + 1) abort();
                 }
                 for (uint32_t q = 0; q < cut0; ++q)
                     if (visited[q]) { table[h[q]] = (uint16_t)(w + q); if (s) s->events++; }
