@@ -471,6 +471,25 @@ def test_many_small_blocks_roundtrip_and_parity(bs):               # SURVEY 8(f4
     assert (dst[clean] == 0).all()
 
 
+def test_concat_batch_compacts_the_strided_blocks(codec):
+    """snp_concat_batch: the compressed blocks sit at a fixed stride after snp_compress_batch; compaction must give exactly
+    their concatenation (what SnappyCompressor.TryCompress produces by advancing its output span, :40-80; what a rank sends in
+    the payload gather)."""
+    cd = codec[O.HASH_CRC32C]
+    nb = 777
+    raw = SD.corpus_blocks([read_testdata(n) for n in CORPUS], 9, nb, SD.MIXED_SEED, "cuda")
+    in_off, in_len = cd.uniform_layout(nb)
+    out, out_off, out_len, status = cd.compress(raw, in_off, in_len)
+    stream, dst_off = cd.compact(out, out_off, out_len)
+    torch.cuda.synchronize()
+    h_out, h_off, h_len = out.cpu().numpy(), out_off.cpu().numpy(), out_len.cpu().numpy()
+    want = b"".join(h_out[h_off[b]: h_off[b] + h_len[b]].tobytes() for b in range(nb))
+    assert stream.cpu().numpy().tobytes() == want
+    assert dst_off.cpu().tolist() == np.concatenate([[0], np.cumsum(h_len[:-1].astype(np.int64))]).tolist()
+    empty, _ = cd.compact(out, out_off[:0], out_len[:0])
+    assert empty.numel() == 0
+
+
 # ------------------------------------------------------------------ CRC-32C
 
 @pytest.mark.parametrize("data,expected", kats.CRC32C)
