@@ -22,7 +22,13 @@ names = ["batches (queued: execution batches)", "tags in batches", "output bytes
          "tags round1", "tags round2", "pattern copies (coop)", "tags in serial loop"]
 for k, nme in enumerate(names):
     print(f"{nme:28s} {buf[k]/nb:12.1f} per block")
-tn = ["wait input window", "parse (decode, chain, scan, enqueue)", "first pass", "extra pass", "serial finish"] if os.environ.get("SNAPPIER_HIP_DECODE", "queued") == "queued" else \
+mode = os.environ.get("SNAPPIER_HIP_DECODE", "chains")
+if mode == "chains":
+    names = ["batches", "tags in batches", "super-windows", "A trips (wave max)", "tags finished one by one", "tags pending after pass 1",
+             "A + overrun trips (wave max)", "chains walked on by the wave", "tags of those walks", "lanes on the true chain"]
+    for k, nme in enumerate(names):
+        print(f"chains: {nme:34s} {buf[k]/nb:12.1f} per block")
+tn = ["stage input", "chains, merge, tag list", "tag bytes, decode, scan, first pass", "extra pass", "serial finish + write-out"] if mode == "chains" else ["wait input window", "parse (decode, chain, scan, enqueue)", "first pass", "extra pass", "serial finish"] if mode == "queued" else \
      ["wait input window", "tag decode + next ptrs", "chain walk", "prefix sum + checks", "copies (all rounds)"]
 tot = sum(buf[10:15])
 for k, nme in enumerate(tn):

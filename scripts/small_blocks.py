@@ -28,4 +28,4 @@ for bs in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096, 16384, 65536]:
     ok = int((st != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and torch.equal(back, raw)
     print(json.dumps({"block_bytes": bs, "blocks": nb, "ok": ok, "ratio": round(float(out_len.sum().item()) / total, 3),
                       "compress_GBps": round(total / ms_c / 1e6, 1), "decompress_GBps": round(total / ms_d / 1e6, 1),
-                      "decode_layout": os.environ.get("SNAPPIER_HIP_DECODE", "queued")}), flush=True)
+                      "decode_layout": os.environ.get("SNAPPIER_HIP_DECODE", "chains")}), flush=True)

@@ -126,6 +126,23 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
     }
 }
 
+// Bytes from the start of the tag whose first 8 bytes are q to the start of the next tag (Constants.cs:42-76: tag byte, 0..4
+// trailer bytes, and the body of a literal).  At least 2; a literal's length saturates so that positions stay below 2^31.
+__device__ __forceinline__ u32 tag_advance(u64 q)
+{
+    const u32 c = static_cast<u32>(q) & 0xffu;
+    const u32 type = c & 3u;
+    const u32 hi6 = c >> 2;
+    const u32 b1234 = static_cast<u32>(q >> 8);
+    const bool is_lit = type == 0;
+    const bool long_lit = is_lit && hi6 >= 60;
+    const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
+    const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
+    const u32 lit_len = (long_lit ? trailer : hi6) + 1u;
+    return 1u + extra + (is_lit ? min(lit_len, 0x40000000u) : 0u);
+}
+__device__ __forceinline__ u64 lds_ld64u(const u8* p) { return reinterpret_cast<const snp_u64_unaligned*>(p)->v; }
+
 #ifndef SNP_D_STAGE
 #define SNP_D_STAGE 2048    // queued mode: a batch whose output is contiguous and at most this long is assembled in LDS (0 = off)
 #endif
@@ -138,6 +155,9 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
 // DS operations of one wavefront execute in order; this only stops the compiler from reordering or forwarding them.
 __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory"); }
 
+#ifndef SNP_D_PF
+#define SNP_D_PF 1          // sub-chain front end: request the next batch's tag bytes while this batch executes
+#endif
 #ifndef SNP_D_PASSES
 #define SNP_D_PASSES 1      // queued mode: extra lane-parallel passes over pending tags before the serial finish
 #endif
@@ -161,7 +181,16 @@ __device__ unsigned long long g_dprof[16];
         dprof_t = now_;                                                           \
     } while (0)
 #define DPROF_FLUSH do { for (int k_ = 0; k_ < 5; ++k_) DPROF_ADD(10 + k_, dprof_acc[k_]); } while (0)
+#define DPROF_TRIP(v) ++(v)
+#define DPROF_ADD_MAX(k, v)                                                                          \
+    do {                                                                                             \
+        u32 m_ = (v);                                                                                \
+        for (int s_ = 32; s_ > 0; s_ >>= 1) m_ = max(m_, static_cast<u32>(__shfl_xor(static_cast<int>(m_), s_, 64)));   \
+        DPROF_ADD(k, m_);                                                                            \
+    } while (0)
 #else
+#define DPROF_TRIP(v)
+#define DPROF_ADD_MAX(k, v)
 #define DPROF_ADD(k, v)
 #define DPROF_T0
 #define DPROF_TIME(k)
@@ -185,15 +214,15 @@ constexpr i32 kIrregular = 99;
 #define SNP_D_OCC
 #endif
 
-template <bool FENCED, int FRONT, bool FRAG>   // FRONT: 0 serial loop only, 1 token-parallel batches, 2 batches feeding a 64-tag execution queue
-__global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __restrict__ in, const u64* __restrict__ in_off,
-                                                        const u32* __restrict__ in_len, u32 nblocks, u8* out,
-                                                        const u64* __restrict__ out_off,
-                                                        const u32* __restrict__ out_cap, u32* __restrict__ out_len,
-                                                        i32* __restrict__ status, const u8* __restrict__ chunk_type,
-                                                        const u32* __restrict__ frag_skip, int redo_only)
+template <bool FENCED, int FRONT, bool FRAG>   // FRONT: 0 serial loop only, 1 token-parallel batches, 2 batches feeding a 64-tag execution queue, 3 sub-chain parse
+__device__ __forceinline__ void decompress_block(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                 const u32* __restrict__ in_len, u32 nblocks, u8* out,
+                                                 const u64* __restrict__ out_off,
+                                                 const u32* __restrict__ out_cap, u32* __restrict__ out_len,
+                                                 i32* __restrict__ status, const u8* __restrict__ chunk_type,
+                                                 const u32* __restrict__ frag_skip, int redo_only)
 {
-    static_assert(!FRAG || FRONT != 1, "fragment mode: serial loop or queued front end");
+    static_assert(!FRAG || (FRONT != 1 && FRONT != 3), "fragment mode: serial loop or queued front end");
     const u32 b = blockIdx.x;
     if (b >= nblocks) return;
     if (redo_only && status[b] != -1) return;            // decompress_small.hip finished this block (it marks the others -1)
@@ -686,6 +715,259 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
         w.wv = 0x80000000u;
     }
 
+    // ---- sub-chain parse feeding lane-parallel execution (FRONT = 3) ------------------------------------------------------------
+    // The 64-byte windows above cost ~160 wave instructions and ~15 dependent LDS round trips per ~21 tags, all to find out
+    // WHERE the tags start.  Here a SUPER-WINDOW of 64 x 32 = 2 KiB of compressed input is staged in LDS and every lane
+    // walks a chain of tags through its own 32-byte region, starting blindly at the region's first byte.  A chain that
+    // starts in the middle of a tag reads garbage, but a garbage chain and the true chain that land on the same byte
+    // are the same chain from there on, and they meet within a few tags.  So:
+    //   A   lane k walks region k from its first byte and records the positions it visits (32-bit mask V_k);
+    //   A'  it walks on past the region's end until it lands on a position the owner of that region has visited (the
+    //       chains have merged: m_k, next lane nx_k), recording these overrun positions too (64-bit mask, two regions);
+    //   R   lane 0's chain is the true one (the super-window starts at a tag): following nx from lane 0 names the lanes
+    //       whose chains are true from their entry m_prev on; a chain that does not merge within two regions is walked
+    //       on by the whole wave, one tag at a time (rare);
+    //   T   true tag starts = each active lane's V_k from its entry on, plus its overrun positions: a 2048-bit map, its
+    //       popcount prefix numbers the tags, and the positions are written out as a u16 list (over the staged input).
+    // ~1 300 wave instructions per ~620 tags (html) instead of ~4 700, and 2 x ~15 dependent LDS reads instead of ~440.
+    // Tags then execute 64 at a time straight from that list: position -> tag bytes (one 8-byte load per lane) -> decode ->
+    // prefix sum of the output lengths -> the staged batch of the queued front end (assembled in LDS, written out coalesced).
+    // A batch ends before the first tag it cannot take (malformed, a literal > 64 bytes, the last 16 output bytes): a long
+    // literal is copied by the whole wave and parsing goes on; anything else falls to the serial loop below.
+    if (FRONT == 3) {
+        constexpr u32 kR = 32;                                          // input bytes per lane region
+        constexpr u32 kW = SNP_WAVE * kR;                               // the super-window
+        __shared__ __attribute__((aligned(16))) u8 c_in[kW + 16];       // its bytes; afterwards the tag positions (u16 each, <= kW / 2 of them)
+        __shared__ __attribute__((aligned(16))) u8 c_stage[SNP_D_STAGE + 64];
+        __shared__ u64 c_busy[65];                                      // batches: pending output bytes; while a super-window is built: V and T
+        u32* const c_V = reinterpret_cast<u32*>(c_busy);
+        u32* const c_T = c_V + SNP_WAVE;
+        u16* const c_pos = reinterpret_cast<u16*>(c_in);
+        const u32 r0 = kR * lane;
+        u32 wbase = ip, ntok = 0, emitted = 0, consumed = 0;
+        u64 q_pf = 0;                                                   // tag bytes of the batch that starts at list index pf_at,
+        u32 pf_at = ~0u;                                                // requested while the batch before it executes
+        DPROF_T0
+        while (st == SNP_OK) {
+            if (emitted == ntok) {
+                // ---- the next super-window ----
+                ip = wbase + consumed;
+                if (ip + 72 > n || op >= expected) break;
+                wbase = ip;
+                const u32 avail = n - wbase;
+                const u32 L = min(kW, avail - 8u);                      // tags may start below L: their 8 bytes lie inside the input
+                const u8* const wsrc = src + wbase;
+#pragma unroll
+                for (u32 i = 0; i < 3; ++i) {
+                    const u32 o = (i * SNP_WAVE + lane) * 16u;
+                    if (o < kW + 16 && o < avail) {
+                        const u32 o2 = min(o, avail - 16u);             // the last piece is pulled back inside the input (avail >= 72)
+                        *reinterpret_cast<snp_u128_unaligned*>(c_in + o2) = *reinterpret_cast<const snp_u128_unaligned*>(wsrc + o2);
+                    }
+                }
+                lanes_sync_lds();
+                DPROF_TIME(10);                                         // input staged
+                // A: the chain from the first byte of the lane's region
+                u32 p = r0, V = 0;
+                [[maybe_unused]] u32 trips = 0;
+                while (p < r0 + kR && p < L) {
+                    V |= 1u << (p - r0);
+                    p += tag_advance(lds_ld64u(c_in + p));
+                    DPROF_TRIP(trips);
+                }
+                DPROF_ADD_MAX(3, trips);                                // loop trips of phase A
+                c_V[lane] = V;
+                c_T[lane] = 0;
+                lanes_sync_lds();
+                // A': on past the region until the chain lands on a position its owner visited
+                u32 m = p, nx = 64u, O0 = 0, O1 = 0;                    // nx: 64 the chain leaves the super-window at m, 65 no merge yet at m
+                const u32 obase = p & ~(kR - 1u);
+                if (p < L) {
+                    for (;;) {
+                        const u32 v = c_V[p >> 5];
+                        if ((v >> (p & 31u)) & 1u) { m = p; nx = p >> 5; break; }
+                        const u32 rel = p - obase;
+                        if (rel >= 64u) { m = p; nx = 65u; break; }
+                        if (rel < 32u) O0 |= 1u << rel;
+                        else O1 |= 1u << (rel - 32u);
+                        p += tag_advance(lds_ld64u(c_in + p));
+                        DPROF_TRIP(trips);
+                        if (p >= L) { m = p; nx = 64u; break; }
+                    }
+                }
+                DPROF_ADD_MAX(6, trips);                                // ... of A and A' together
+                // R: the true chain, lane to lane
+                u64 active = 0;
+                u32 entry = 0;
+                for (u32 k = 0, e = 0;;) {
+                    active |= 1ull << k;
+                    entry = lane == k ? e : entry;
+                    u32 mk = read_lane(m, k), nk = read_lane(nx, k);
+                    if (nk == 65u) {                                    // walk on, whole wave, until it merges or leaves
+                        DPROF_ADD(7, 1);
+                        nk = 64u;
+                        while (mk < L) {
+                            const u32 v = bcast_first(c_V[mk >> 5]);
+                            if ((v >> (mk & 31u)) & 1u) { nk = mk >> 5; break; }
+                            if (lane == 0) atomicOr(&c_T[mk >> 5], 1u << (mk & 31u));
+                            mk += bcast_first(tag_advance(lds_ld64u(c_in + mk)));
+                            DPROF_ADD(8, 1);
+                        }
+                    }
+                    if (nk >= 64u) { consumed = mk; break; }
+                    e = mk;
+                    k = nk;
+                }
+                // T: the true tag starts
+                if ((active >> lane) & 1ull) {
+                    const u32 own = V & ~((1u << (entry & 31u)) - 1u);
+                    const u32 w0 = obase >> 5;
+                    if (own) atomicOr(&c_T[lane], own);
+                    if (O0 && w0 < SNP_WAVE) atomicOr(&c_T[w0], O0);
+                    if (O1 && w0 + 1 < SNP_WAVE) atomicOr(&c_T[w0 + 1], O1);
+                }
+                lanes_sync_lds();
+                const u32 Tw = c_T[lane];
+                const u32 cnt = static_cast<u32>(__builtin_popcount(Tw));
+                const u32 cincl = wave_inclusive_scan(cnt);
+                ntok = read_lane(cincl, 63);
+                lanes_sync_lds();                                       // (every read of c_in is done: the list overwrites it)
+                u32 t = cincl - cnt, bits = Tw;
+                while (bits) {
+                    c_pos[t++] = static_cast<u16>(r0 + static_cast<u32>(__builtin_ctz(bits)));
+                    bits &= bits - 1u;
+                }
+                lanes_sync_lds();
+                emitted = 0;
+                pf_at = ~0u;
+                DPROF_ADD(2, 1);                                        // super-windows
+                DPROF_ADD(9, __builtin_popcountll(active));             // lanes on the true chain
+                DPROF_TIME(11);                                         // chains, merge, tag list
+            }
+            // ---- one batch: the next <= 64 tags of the list ----
+            const u32 t = emitted + lane;
+            const bool have = t < ntok;
+            const u32 pos = have ? c_pos[t] : 0u;
+            const u64 q = pf_at == emitted ? q_pf : ld64u(src + wbase + pos);   // pos < L (idle lanes re-read position 0)
+            const u32 c = static_cast<u32>(q) & 0xffu;
+            const u32 type = c & 3u;
+            const u32 hi6 = c >> 2;
+            const u32 b1234 = static_cast<u32>(q >> 8);
+            const bool is_lit = type == 0;
+            const bool long_lit = is_lit && hi6 >= 60;
+            const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
+            const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
+            const u32 len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);
+            const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
+            const u32 body = pos + 1u + extra;                          // a literal's bytes, from wbase
+            const u32 olen = have ? len : 0u;
+            const u32 incl = wave_inclusive_scan(olen);
+            const u32 ostart = op + incl - olen;
+            const u32 room = n - wbase - 16u;                           // lane_copy over-reads 15 bytes
+            const bool lit_ok = ((len - 1u) < room) & (body <= room - len);
+            const bool copy_ok = (off - 1u) < ostart;
+            const bool ok = have & ((is_lit & lit_ok) | (!is_lit & copy_ok)) & (incl + 16u <= expected - op);
+            const bool big = is_lit & (len > 64u);
+            const u64 okm = ballot64(ok & !big & (incl <= SNP_D_STAGE));
+            const u32 ne = okm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~okm));
+            if (ne == 0) {
+                const u32 f0 = read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), 0);
+                if (f0 != 3u) {                                         // not ours: the serial loop decides, from this tag on
+                    ip = wbase + read_lane(pos, 0);
+                    emitted = ntok = consumed = 0;                      // (ip is final)
+                    wbase = ip;
+                    break;
+                }
+                const u32 l0 = read_lane(len, 0);
+                wave_copy(dst + op, src + wbase + read_lane(body, 0), l0, lane);
+                op += l0;
+                emitted += 1;
+                continue;
+            }
+            const bool act = lane < ne;
+            const u32 mark = op;                                        // all output below it is complete
+            const u32 span = read_lane(incl, ne - 1);
+            const bool ready = act && (is_lit || (off >= len && ostart - off + len <= mark));
+            if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pf_at = SNP_D_PF ? emitted + ne : ~0u;                      // the next batch's tag bytes travel with this batch's copies
+            if (pf_at < ntok) q_pf = ld64u(src + wbase + (pf_at + lane < ntok ? c_pos[pf_at + lane] : 0u));
+            u8* const my = c_stage + (ostart - mark);
+            const u32 s_lo = ostart - off;
+            if (ready) lane_copy(my, is_lit ? src + wbase + body : dst + s_lo, len);
+            u64 pend = ballot64(act && !ready);
+            DPROF_ADD(0, 1);
+            DPROF_ADD(1, ne);
+            DPROF_ADD(5, __builtin_popcountll(pend));
+            DPROF_TIME(12);                                             // tag bytes, decode, prefix sum, first pass
+            if (pend) {
+                // second lane-parallel pass: sources inside the batch that no pending tag still has to write
+                bool blocked = off < len || s_lo < mark;                // pattern copies and sources straddling `mark`: finished in order
+                const bool mine = (pend >> lane) & 1ull;
+                if (pend & (pend - 1)) {
+                    c_busy[lane] = 0ull;
+                    lanes_sync_lds();
+                    if (mine) {
+                        const u32 r = ostart - mark, b0 = r & 63u;
+                        const u64 mk = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+                        atomicOr(reinterpret_cast<unsigned long long*>(&c_busy[r >> 6]), static_cast<unsigned long long>(mk << b0));
+                        if (b0 && (mk >> (64u - b0)))
+                            atomicOr(reinterpret_cast<unsigned long long*>(&c_busy[(r >> 6) + 1]), static_cast<unsigned long long>(mk >> (64u - b0)));
+                    }
+                    lanes_sync_lds();
+                    if (mine && !blocked) {
+                        const u32 lo = s_lo - mark, b0 = lo & 63u;
+                        const u64 mk = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+                        const u64 w0 = c_busy[lo >> 6], w1 = c_busy[(lo >> 6) + 1];
+                        blocked = ((w0 & (mk << b0)) | (b0 ? (w1 & (mk >> (64u - b0))) : 0ull)) != 0ull;
+                    }
+                }
+                const bool ready2 = mine && !blocked;
+                lanes_sync_lds();
+                if (ready2) lane_copy(my, c_stage + (s_lo - mark), len);
+                pend &= ~ballot64(ready2);
+                DPROF_ADD(4, __builtin_popcountll(pend));
+                DPROF_TIME(13);
+                while (pend) {                                          // the rest in order, whole wave per tag, a byte per lane
+                    const u32 f = static_cast<u32>(__builtin_ctzll(pend));
+                    pend &= pend - 1;
+                    const u32 f_o = read_lane(ostart, f), f_off = read_lane(off, f), f_len = read_lane(len, f);
+                    u32 sidx = lane;
+                    if (f_off < f_len) {
+#pragma unroll
+                        for (int sh = 5; sh >= 0; --sh) {
+                            const u32 tt = f_off << sh;
+                            sidx = min(sidx, sidx - tt);
+                        }
+                    }
+                    const u32 spos = f_o - f_off + sidx;                // output position this lane's byte comes from
+                    lanes_sync_lds();
+                    u32 byte = 0;
+                    if (f_o - f_off >= mark) {                          // the whole source lies in this batch
+                        if (lane < f_len) byte = c_stage[spos - mark];
+                    } else if (lane < f_len) {                          // it starts before the batch: those bytes are in global memory
+                        if (spos < mark) byte = dst[spos];
+                        else byte = c_stage[spos - mark];
+                    }
+                    lanes_sync_lds();
+                    if (lane < f_len) c_stage[f_o - mark + lane] = static_cast<u8>(byte);
+                }
+            }
+            // the whole run, coalesced
+            lanes_sync_lds();
+            u8* const g = dst + mark;
+            for (u32 i = lane * 16; i + 16 <= span; i += SNP_WAVE * 16)
+                *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(c_stage + i);
+            const u32 tail = span & ~15u;
+            if (tail + lane < span) g[tail + lane] = c_stage[tail + lane];
+            lanes_sync_lds();
+            op += span;
+            emitted += ne;
+            DPROF_TIME(14);
+        }
+        DPROF_FLUSH;
+        w.wv = 0x80000000u;
+    }
+
     u32 fenced = 0;   // output bytes below this are known to have left the wave's store queue (FENCED only)
 
     // ---- tag loop  (SnappyDecompressor.cs:234-341) -----------------------------------------------------------
@@ -763,6 +1045,29 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(const u8* __r
     }
 }
 
+#define SNP_D_PARAMS                                                                                                  \
+    const u8 *__restrict__ in, const u64 *__restrict__ in_off, const u32 *__restrict__ in_len, u32 nblocks, u8 *out,  \
+        const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap, u32 *__restrict__ out_len,                 \
+        i32 *__restrict__ status, const u8 *__restrict__ chunk_type, const u32 *__restrict__ frag_skip, int redo_only
+#define SNP_D_ARGS in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, frag_skip, redo_only
+
+template <bool FENCED, int FRONT, bool FRAG>
+__global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(SNP_D_PARAMS)
+{
+    decompress_block<FENCED, FRONT, FRAG>(SNP_D_ARGS);
+}
+
+// The sub-chain front end needs 68 VGPRs left to itself; at 64 (two spilled) it runs eight wavefronts per SIMD instead of
+// seven: measured 677 -> 711 GB/s (html-like, 65 536 blocks; profiles/r02m_chains_variants.jsonl).
+#ifndef SNP_D_CHAIN_WAVES
+#define SNP_D_CHAIN_WAVES 8
+#endif
+template <bool FENCED>
+__global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_CHAIN_WAVES, SNP_D_CHAIN_WAVES))) void k_decompress_chains(SNP_D_PARAMS)
+{
+    decompress_block<FENCED, 3, false>(SNP_D_ARGS);
+}
+
 }  // namespace
 
 #if SNP_D_PROF
@@ -781,7 +1086,7 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
                                             const u64* out_off, const u32* out_cap, u32* out_len, i32* status,
                                             const u8* chunk_type, int mode, hipStream_t stream, const u32* frag_skip)
 {
-    // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end), bit 2: batches without the execution queue;
+    // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end), bit 2: batches without the execution queue, bit 3: sub-chain parse;
     // bit 4: only the blocks decompress_small.hip left marked -1;  bits 8..: dynamic LDS bytes / 256 requested per wavefront purely to cap how many blocks a CU decodes at once
     if (nblocks == 0) return hipSuccess;
     const unsigned lds_bytes = static_cast<unsigned>(mode >> 8) * 256u;
@@ -798,6 +1103,15 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
             case 2: case 6: SNP_LAUNCH_FRAG(false, 0); break;
             default: SNP_LAUNCH_FRAG(true, 0); break;
         }
+        return hipGetLastError();
+    }
+    if (mode & 8) {                                     // sub-chain parse
+        if (mode & 1)
+            hipLaunchKernelGGL((k_decompress_chains<true>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,
+                               nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr, (mode >> 4) & 1);
+        else
+            hipLaunchKernelGGL((k_decompress_chains<false>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,
+                               nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr, (mode >> 4) & 1);
         return hipGetLastError();
     }
     switch (mode & 7) {

@@ -145,7 +145,7 @@ def corrupt(rng: np.random.Generator, z: np.ndarray) -> np.ndarray:
     return z
 
 
-@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "small"])
+@pytest.mark.parametrize("decode", ["queued", "chains", "batched", "serial", "small"])
 def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatch):
     if decode == "small":       # every block first goes through the block-per-lane kernel (decompress_small.hip), whatever its size
         monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")

@@ -396,7 +396,7 @@ def test_compress_layouts_are_bit_identical(layout, monkeypatch):
                         O.compress(read_testdata(name), variant))
 
 
-@pytest.mark.parametrize("decode", ["queued", "batched", "serial", "small"])
+@pytest.mark.parametrize("decode", ["queued", "chains", "batched", "serial", "small"])
 @pytest.mark.parametrize("fenced", ["0", "1"])
 def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     """Same-wave store->load ordering: the default kernel relies on in-order vector memory; the fenced variant drains
