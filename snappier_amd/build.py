@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fconstexpr-steps=100000000", "-Wall",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fconstexpr-steps=100000000", "-Wall", "-Wno-sometimes-uninitialized",
          "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib"]
 
 LIBS = {

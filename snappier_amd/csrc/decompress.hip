@@ -126,6 +126,52 @@ __device__ __forceinline__ void lane_copy(u8* d, const u8* s, u32 len)
     }
 }
 
+// lane_copy in two halves, so that a pass first REQUESTS every piece of every lane's copy (one memory round trip for the whole
+// pass: lane_copy's ladder waits for one piece before it asks for the next, up to four round trips for a 64-byte tag) and
+// then stores them.  Same over-read contract as lane_copy.  (Plain vector values, not a struct behind a reference: that
+// one ended up in scratch memory.)
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld128u(const u8* p)
+{
+    const snp_u128_unaligned t = *reinterpret_cast<const snp_u128_unaligned*>(p);
+    return u32x4{t.v[0], t.v[1], t.v[2], t.v[3]};
+}
+__device__ __forceinline__ void st128u(u8* p, u32x4 v)
+{
+    snp_u128_unaligned t;
+    t.v[0] = v.x; t.v[1] = v.y; t.v[2] = v.z; t.v[3] = v.w;
+    *reinterpret_cast<snp_u128_unaligned*>(p) = t;
+}
+// One lane copies len (1..64) bytes, requesting its pieces in pairs: head + tail first (every copy of <= 32 bytes is one round
+// trip), then the two middle pieces of a longer one.
+__device__ __forceinline__ void lane_copy2(u8* d, const u8* s, u32 len)
+{
+    const u32x4 p0 = ld128u(s);
+    u32x4 p1;                                                           // read only where it was loaded
+    if (len > 16) p1 = ld128u(s + len - 16);
+    if (len >= 16) {
+        st128u(d, p0);
+        if (len > 16) st128u(d + len - 16, p1);
+    } else {
+        const bool c8 = (len & 8u) != 0, c4 = (len & 4u) != 0, c2 = (len & 2u) != 0;
+        const u32 a0 = c8 ? p0.z : p0.x;
+        const u32 a1 = c8 ? p0.w : p0.y;
+        const u32 b0 = c4 ? a1 : a0;
+        const u32 c0 = c2 ? b0 >> 16 : b0;
+        const u32 o4 = len & 8u, o2 = len & 12u, o1 = len & 14u;
+        if (c8) reinterpret_cast<snp_u64_unaligned*>(d)->v = p0.x | (static_cast<u64>(p0.y) << 32);
+        if (c4) st32u(d + o4, a0);
+        if (c2) reinterpret_cast<snp_u16_unaligned*>(d + o2)->v = static_cast<u16>(b0);
+        if (len & 1u) d[o1] = static_cast<u8>(c0);
+    }
+    if (len > 32) {
+        const u32x4 p2 = ld128u(s + 16), p3 = ld128u(s + min(32u, len - 16u));   // (unconditional: both in flight together;
+        asm volatile("" ::"v"(p2), "v"(p3));                                     //  the compiler must not sink the second one)
+        st128u(d + 16, p2);
+        if (len > 48) st128u(d + 32, p3);
+    }
+}
+
 // Bytes from the start of the tag whose first 8 bytes are q to the start of the next tag (Constants.cs:42-76: tag byte, 0..4
 // trailer bytes, and the body of a literal).  At least 2; a literal's length saturates so that positions stay below 2^31.
 __device__ __forceinline__ u32 tag_advance(u64 q)
@@ -737,7 +783,8 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
     if (FRONT == 3) {
         constexpr u32 kR = 32;                                          // input bytes per lane region
         constexpr u32 kW = SNP_WAVE * kR;                               // the super-window
-        __shared__ __attribute__((aligned(16))) u8 c_in[kW + 16];       // its bytes; afterwards the tag positions (u16 each, <= kW / 2 of them)
+        constexpr u32 kCap = 128;                                       // a chain may overrun its region by this much before the wave takes over
+        __shared__ __attribute__((aligned(16))) u8 c_in[kW];            // its bytes; afterwards the tag positions (u16 each, < kW / 2 of them)
         __shared__ __attribute__((aligned(16))) u8 c_stage[SNP_D_STAGE + 64];
         __shared__ u64 c_busy[65];                                      // batches: pending output bytes; while a super-window is built: V and T
         u32* const c_V = reinterpret_cast<u32*>(c_busy);
@@ -755,46 +802,55 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 if (ip + 72 > n || op >= expected) break;
                 wbase = ip;
                 const u32 avail = n - wbase;
-                const u32 L = min(kW, avail - 8u);                      // tags may start below L: their 8 bytes lie inside the input
+                const u32 L = min(kW, avail) - 8u;                      // tags may start below L: their 8 bytes lie inside the staged input
                 const u8* const wsrc = src + wbase;
-#pragma unroll
-                for (u32 i = 0; i < 3; ++i) {
-                    const u32 o = (i * SNP_WAVE + lane) * 16u;
-                    if (o < kW + 16 && o < avail) {
-                        const u32 o2 = min(o, avail - 16u);             // the last piece is pulled back inside the input (avail >= 72)
-                        *reinterpret_cast<snp_u128_unaligned*>(c_in + o2) = *reinterpret_cast<const snp_u128_unaligned*>(wsrc + o2);
-                    }
+                {
+                    // 2 x 16 bytes per lane; a piece that would cross the end of the input is pulled back inside it (avail >= 72;
+                    // the bytes it rewrites are the same bytes), pieces beyond it are not needed
+                    const u32 oa = lane * 16u, ob = oa + 1024u;
+                    const u32 la = min(oa, avail - 16u), lb = min(ob, avail - 16u);
+                    const u32x4 va = ld128u(wsrc + la), vb = ld128u(wsrc + lb);
+                    st128u(c_in + la, va);
+                    st128u(c_in + lb, vb);
                 }
                 lanes_sync_lds();
                 DPROF_TIME(10);                                         // input staged
                 // A: the chain from the first byte of the lane's region
                 u32 p = r0, V = 0;
                 [[maybe_unused]] u32 trips = 0;
-                while (p < r0 + kR && p < L) {
-                    V |= 1u << (p - r0);
-                    p += tag_advance(lds_ld64u(c_in + p));
-                    DPROF_TRIP(trips);
+                {
+                    const u32 lim = min(r0 + kR, L);
+                    while (p < lim) {
+                        V |= 1u << (p - r0);
+                        p += tag_advance(lds_ld64u(c_in + p));
+                        DPROF_TRIP(trips);
+                    }
                 }
                 DPROF_ADD_MAX(3, trips);                                // loop trips of phase A
                 c_V[lane] = V;
                 c_T[lane] = 0;
                 lanes_sync_lds();
-                // A': on past the region until the chain lands on a position its owner visited
-                u32 m = p, nx = 64u, O0 = 0, O1 = 0;                    // nx: 64 the chain leaves the super-window at m, 65 no merge yet at m
+                // A': on past the region until the chain lands on a position its owner visited (one loop exit: the exec-mask
+                // bookkeeping of a divergent loop is scalar work, and the scalar unit is the busiest one in this kernel)
+                u32 nx = 64u;                                           // 64: the chain leaves the super-window, 65: no merge within kCap bytes
+                u32 O[kCap / 32] = {};                                  // overrun positions, from obase
                 const u32 obase = p & ~(kR - 1u);
-                if (p < L) {
-                    for (;;) {
-                        const u32 v = c_V[p >> 5];
-                        if ((v >> (p & 31u)) & 1u) { m = p; nx = p >> 5; break; }
-                        const u32 rel = p - obase;
-                        if (rel >= 64u) { m = p; nx = 65u; break; }
-                        if (rel < 32u) O0 |= 1u << rel;
-                        else O1 |= 1u << (rel - 32u);
-                        p += tag_advance(lds_ld64u(c_in + p));
-                        DPROF_TRIP(trips);
-                        if (p >= L) { m = p; nx = 64u; break; }
-                    }
+                for (bool go = p < L; go;) {
+                    const u32 v = c_V[p >> 5];
+                    const u64 qq = lds_ld64u(c_in + p);
+                    asm volatile("" ::"v"(v), "v"(qq));                 // (both reads in flight together: one LDS round trip per tag)
+                    const u32 rel = p - obase;
+                    const bool hit = (v >> (p & 31u)) & 1u;
+                    const bool stop = hit | (rel >= kCap);
+                    nx = stop ? (hit ? p >> 5 : 65u) : nx;
+                    const u32 bit = stop ? 0u : 1u << (rel & 31u);
+#pragma unroll
+                    for (u32 w = 0; w < kCap / 32; ++w) O[w] |= (rel >> 5) == w ? bit : 0u;
+                    p = stop ? p : p + tag_advance(qq);
+                    go = !stop & (p < L);
+                    DPROF_TRIP(trips);
                 }
+                const u32 m = p;                                        // where the chain merged, gave up or left
                 DPROF_ADD_MAX(6, trips);                                // ... of A and A' together
                 // R: the true chain, lane to lane
                 u64 active = 0;
@@ -823,8 +879,9 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     const u32 own = V & ~((1u << (entry & 31u)) - 1u);
                     const u32 w0 = obase >> 5;
                     if (own) atomicOr(&c_T[lane], own);
-                    if (O0 && w0 < SNP_WAVE) atomicOr(&c_T[w0], O0);
-                    if (O1 && w0 + 1 < SNP_WAVE) atomicOr(&c_T[w0 + 1], O1);
+#pragma unroll
+                    for (u32 w = 0; w < kCap / 32; ++w)
+                        if (O[w] && w0 + w < SNP_WAVE) atomicOr(&c_T[w0 + w], O[w]);
                 }
                 lanes_sync_lds();
                 const u32 Tw = c_T[lane];
@@ -893,7 +950,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             if (pf_at < ntok) q_pf = ld64u(src + wbase + (pf_at + lane < ntok ? c_pos[pf_at + lane] : 0u));
             u8* const my = c_stage + (ostart - mark);
             const u32 s_lo = ostart - off;
-            if (ready) lane_copy(my, is_lit ? src + wbase + body : dst + s_lo, len);
+            if (ready) lane_copy2(my, is_lit ? src + wbase + body : dst + s_lo, len);
             u64 pend = ballot64(act && !ready);
             DPROF_ADD(0, 1);
             DPROF_ADD(1, ne);
@@ -923,7 +980,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 }
                 const bool ready2 = mine && !blocked;
                 lanes_sync_lds();
-                if (ready2) lane_copy(my, c_stage + (s_lo - mark), len);
+                if (ready2) lane_copy2(my, c_stage + (s_lo - mark), len);
                 pend &= ~ballot64(ready2);
                 DPROF_ADD(4, __builtin_popcountll(pend));
                 DPROF_TIME(13);
