@@ -149,6 +149,14 @@ __device__ __forceinline__ void lane_copy2(u8* d, const u8* s, u32 len)
     const u32x4 p0 = ld128u(s);
     u32x4 p1;                                                           // read only where it was loaded
     if (len > 16) p1 = ld128u(s + len - 16);
+#if SNP_D_PIECES == 4
+    u32x4 p2, p3;                                                       // all four pieces in flight together (8 more VGPRs)
+    if (len > 32) {
+        p2 = ld128u(s + 16);
+        p3 = ld128u(s + min(32u, len - 16u));
+        asm volatile("" ::"v"(p2), "v"(p3));
+    }
+#endif
     if (len >= 16) {
         st128u(d, p0);
         if (len > 16) st128u(d + len - 16, p1);
@@ -165,8 +173,10 @@ __device__ __forceinline__ void lane_copy2(u8* d, const u8* s, u32 len)
         if (len & 1u) d[o1] = static_cast<u8>(c0);
     }
     if (len > 32) {
+#if SNP_D_PIECES != 4
         const u32x4 p2 = ld128u(s + 16), p3 = ld128u(s + min(32u, len - 16u));   // (unconditional: both in flight together;
         asm volatile("" ::"v"(p2), "v"(p3));                                     //  the compiler must not sink the second one)
+#endif
         st128u(d + 16, p2);
         if (len > 48) st128u(d + 32, p3);
     }
@@ -176,16 +186,17 @@ __device__ __forceinline__ void lane_copy2(u8* d, const u8* s, u32 len)
 // trailer bytes, and the body of a literal).  At least 2; a literal's length saturates so that positions stay below 2^31.
 __device__ __forceinline__ u32 tag_advance(u64 q)
 {
-    const u32 c = static_cast<u32>(q) & 0xffu;
-    const u32 type = c & 3u;
-    const u32 hi6 = c >> 2;
-    const u32 b1234 = static_cast<u32>(q >> 8);
-    const bool is_lit = type == 0;
-    const bool long_lit = is_lit && hi6 >= 60;
-    const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
-    const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
-    const u32 lit_len = (long_lit ? trailer : hi6) + 1u;
-    return 1u + extra + (is_lit ? min(lit_len, 0x40000000u) : 0u);
+    const u32 lo = static_cast<u32>(q);
+    const u32 t = lo & 3u;
+    const u32 h = __builtin_amdgcn_ubfe(lo, 2u, 6u);
+    u32 adv = t ? __builtin_amdgcn_ubfe(0x05030200u, 8u * t, 8u) : h + 2u;   // copy-1/2/4: 2, 3, 5 bytes; short literal: tag + h + 1
+    if (__builtin_expect((lo & 0xf3u) == 0xf0u, 0)) {                        // literal with 1..4 length bytes (rare: kept out of the common path)
+        const u32 ex = h - 59u;
+        const u32 b1234 = static_cast<u32>(q >> 8);
+        const u32 tr = ex >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * ex);
+        adv = 2u + ex + min(tr, 0x3fffffffu);
+    }
+    return adv;
 }
 __device__ __forceinline__ u64 lds_ld64u(const u8* p) { return reinterpret_cast<const snp_u64_unaligned*>(p)->v; }
 
@@ -201,6 +212,9 @@ __device__ __forceinline__ u64 lds_ld64u(const u8* p) { return reinterpret_cast<
 // DS operations of one wavefront execute in order; this only stops the compiler from reordering or forwarding them.
 __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory"); }
 
+#ifndef SNP_D_PIECES
+#define SNP_D_PIECES 2      // lane_copy2: pieces requested together (2: head + tail, then the middle pair; 4: all at once)
+#endif
 #ifndef SNP_D_PF
 #define SNP_D_PF 1          // sub-chain front end: request the next batch's tag bytes while this batch executes
 #endif
@@ -852,14 +866,44 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 }
                 const u32 m = p;                                        // where the chain merged, gave up or left
                 DPROF_ADD_MAX(6, trips);                                // ... of A and A' together
-                // R: the true chain, lane to lane
-                u64 active = 0;
+                // R: the lanes on the true chain = the lanes reachable from lane 0 along nx, by pointer doubling (flags through
+                // LDS: a scatter needs its senders masked); each of them tells its successor where it enters.  ~70 wave
+                // instructions instead of a scalar walk of ~14 per lane on the chain (~46 of them on html).
+                u64 active;
                 u32 entry = 0;
+                {
+                    u8* const c_reach = c_stage;                        // (the stage is idle while a super-window is built)
+                    u32* const c_entry = reinterpret_cast<u32*>(c_stage + SNP_WAVE);
+                    u32 hop = nx;
+                    bool reached = lane == 0;
+                    c_reach[lane] = reached ? 1 : 0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        lanes_sync_lds();
+                        if (reached && hop < 64u) c_reach[hop] = 1;
+                        lanes_sync_lds();
+                        reached = c_reach[lane] != 0;
+                        const u32 h2 = bperm(hop, hop);
+                        hop = hop < 64u ? h2 : hop;
+                    }
+                    if (reached && nx < 64u) c_entry[nx] = m;
+                    lanes_sync_lds();
+                    if (lane) entry = c_entry[lane];
+                    lanes_sync_lds();
+                    active = ballot64(reached);
+                    const u64 ends = ballot64(reached && nx == 64u);    // the lane whose chain leaves the super-window, if the chain gets there
+                    consumed = ends ? read_lane(m, static_cast<u32>(__builtin_ctzll(ends))) : 0u;
+                }
+                if (ballot64(((active >> lane) & 1ull) && nx == 65u)) {
+                // a chain on the true path did not merge within kCap bytes (rare: ~2 per block on html): follow the path lane by
+                // lane on the scalar unit instead, walking such a chain on, whole wave, until it merges or leaves
+                active = 0;
+                entry = 0;
                 for (u32 k = 0, e = 0;;) {
                     active |= 1ull << k;
                     entry = lane == k ? e : entry;
                     u32 mk = read_lane(m, k), nk = read_lane(nx, k);
-                    if (nk == 65u) {                                    // walk on, whole wave, until it merges or leaves
+                    if (nk == 65u) {
                         DPROF_ADD(7, 1);
                         nk = 64u;
                         while (mk < L) {
@@ -873,6 +917,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     if (nk >= 64u) { consumed = mk; break; }
                     e = mk;
                     k = nk;
+                }
                 }
                 // T: the true tag starts
                 if ((active >> lane) & 1ull) {
@@ -984,7 +1029,10 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 pend &= ~ballot64(ready2);
                 DPROF_ADD(4, __builtin_popcountll(pend));
                 DPROF_TIME(13);
-                while (pend) {                                          // the rest in order, whole wave per tag, a byte per lane
+                // The rest in order, whole wave per tag, a byte per lane.  (This loop runs ~5 times per batch and is mostly scalar
+                // work -- the busiest unit of this kernel -- so the common case, a source inside the stage, is kept to one
+                // LDS read and one LDS write under one exec mask; LDS operations of a wave execute in order.)
+                while (pend) {
                     const u32 f = static_cast<u32>(__builtin_ctzll(pend));
                     pend &= pend - 1;
                     const u32 f_o = read_lane(ostart, f), f_off = read_lane(off, f), f_len = read_lane(len, f);
@@ -996,17 +1044,18 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                             sidx = min(sidx, sidx - tt);
                         }
                     }
-                    const u32 spos = f_o - f_off + sidx;                // output position this lane's byte comes from
-                    lanes_sync_lds();
-                    u32 byte = 0;
-                    if (f_o - f_off >= mark) {                          // the whole source lies in this batch
-                        if (lane < f_len) byte = c_stage[spos - mark];
-                    } else if (lane < f_len) {                          // it starts before the batch: those bytes are in global memory
-                        if (spos < mark) byte = dst[spos];
-                        else byte = c_stage[spos - mark];
+                    const u32 rel = f_o - mark;
+                    if (rel >= f_off) {                                 // the whole source lies in this batch
+                        if (lane < f_len) c_stage[rel + lane] = c_stage[rel - f_off + sidx];
+                    } else {                                            // it starts before the batch: those bytes are in global memory
+                        const u32 spos = f_o - f_off + sidx;
+                        u32 byte = 0;
+                        if (lane < f_len) {
+                            if (spos < mark) byte = dst[spos];
+                            else byte = c_stage[spos - mark];
+                        }
+                        if (lane < f_len) c_stage[rel + lane] = static_cast<u8>(byte);
                     }
-                    lanes_sync_lds();
-                    if (lane < f_len) c_stage[f_o - mark + lane] = static_cast<u8>(byte);
                 }
             }
             // the whole run, coalesced
