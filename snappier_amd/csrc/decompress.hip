@@ -198,6 +198,23 @@ __device__ __forceinline__ u32 tag_advance(u64 q)
     }
     return adv;
 }
+// The same from a staged copy of the input: only the tag BYTE is read (ds_read_u8 -- an 8-byte read at an arbitrary address
+// stalls the LDS pipe: SQ_LDS_UNALIGNED_STALL was a third of this kernel's LDS time); the length bytes of a long literal are
+// fetched in the rare branch.
+__device__ __forceinline__ u32 tag_advance_staged(const u8* at)
+{
+    const u32 c = at[0];
+    const u32 t = c & 3u;
+    const u32 h = c >> 2;
+    u32 adv = t ? __builtin_amdgcn_ubfe(0x05030200u, 8u * t, 8u) : h + 2u;
+    if (__builtin_expect((c & 0xf3u) == 0xf0u, 0)) {
+        const u32 ex = h - 59u;
+        const u32 b1234 = reinterpret_cast<const snp_u32_unaligned*>(at + 1)->v;
+        const u32 tr = ex >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * ex);
+        adv = 2u + ex + min(tr, 0x3fffffffu);
+    }
+    return adv;
+}
 __device__ __forceinline__ u64 lds_ld64u(const u8* p) { return reinterpret_cast<const snp_u64_unaligned*>(p)->v; }
 
 #ifndef SNP_D_STAGE
@@ -212,6 +229,12 @@ __device__ __forceinline__ u64 lds_ld64u(const u8* p) { return reinterpret_cast<
 // DS operations of one wavefront execute in order; this only stops the compiler from reordering or forwarding them.
 __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory"); }
 
+#ifndef SNP_D_ABLATE
+#define SNP_D_ABLATE 0      // TIMING-ONLY ablations of the sub-chain front end (the output is wrong): 1 no first-pass copies, 2 no serial finish,
+#endif                      // 4 no write-out, 8 no tag-byte load (decode garbage-free zeros), 16 no second pass
+#ifndef SNP_D_PASS2
+#define SNP_D_PASS2 1       // sub-chain front end: second lane-parallel pass over the tags pass 1 could not take (0: they all finish one by one)
+#endif
 #ifndef SNP_D_PIECES
 #define SNP_D_PIECES 2      // lane_copy2: pieces requested together (2: head + tail, then the middle pair; 4: all at once)
 #endif
@@ -836,7 +859,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     const u32 lim = min(r0 + kR, L);
                     while (p < lim) {
                         V |= 1u << (p - r0);
-                        p += tag_advance(lds_ld64u(c_in + p));
+                        p += tag_advance_staged(c_in + p);
                         DPROF_TRIP(trips);
                     }
                 }
@@ -847,20 +870,19 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 // A': on past the region until the chain lands on a position its owner visited (one loop exit: the exec-mask
                 // bookkeeping of a divergent loop is scalar work, and the scalar unit is the busiest one in this kernel)
                 u32 nx = 64u;                                           // 64: the chain leaves the super-window, 65: no merge within kCap bytes
-                u32 O[kCap / 32] = {};                                  // overrun positions, from obase
+                u32* const c_O = reinterpret_cast<u32*>(c_stage + 512) + lane * (kCap / 32);   // overrun positions, a bit each, from obase
+#pragma unroll                                                          // (in the idle stage: keeping them in registers costs 20 instructions per trip)
+                for (u32 w = 0; w < kCap / 32; ++w) c_O[w] = 0;
                 const u32 obase = p & ~(kR - 1u);
                 for (bool go = p < L; go;) {
                     const u32 v = c_V[p >> 5];
-                    const u64 qq = lds_ld64u(c_in + p);
-                    asm volatile("" ::"v"(v), "v"(qq));                 // (both reads in flight together: one LDS round trip per tag)
+                    const u32 adv = tag_advance_staged(c_in + p);
                     const u32 rel = p - obase;
                     const bool hit = (v >> (p & 31u)) & 1u;
                     const bool stop = hit | (rel >= kCap);
                     nx = stop ? (hit ? p >> 5 : 65u) : nx;
-                    const u32 bit = stop ? 0u : 1u << (rel & 31u);
-#pragma unroll
-                    for (u32 w = 0; w < kCap / 32; ++w) O[w] |= (rel >> 5) == w ? bit : 0u;
-                    p = stop ? p : p + tag_advance(qq);
+                    atomicOr(&c_O[min(rel >> 5, kCap / 32 - 1)], stop ? 0u : 1u << (rel & 31u));   // (unconditional: no exec-mask bookkeeping)
+                    p = stop ? p : p + adv;
                     go = !stop & (p < L);
                     DPROF_TRIP(trips);
                 }
@@ -910,7 +932,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                             const u32 v = bcast_first(c_V[mk >> 5]);
                             if ((v >> (mk & 31u)) & 1u) { nk = mk >> 5; break; }
                             if (lane == 0) atomicOr(&c_T[mk >> 5], 1u << (mk & 31u));
-                            mk += bcast_first(tag_advance(lds_ld64u(c_in + mk)));
+                            mk += bcast_first(tag_advance_staged(c_in + mk));
                             DPROF_ADD(8, 1);
                         }
                     }
@@ -925,8 +947,10 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     const u32 w0 = obase >> 5;
                     if (own) atomicOr(&c_T[lane], own);
 #pragma unroll
-                    for (u32 w = 0; w < kCap / 32; ++w)
-                        if (O[w] && w0 + w < SNP_WAVE) atomicOr(&c_T[w0 + w], O[w]);
+                    for (u32 w = 0; w < kCap / 32; ++w) {
+                        const u32 ow = c_O[w];
+                        if (ow && w0 + w < SNP_WAVE) atomicOr(&c_T[w0 + w], ow);
+                    }
                 }
                 lanes_sync_lds();
                 const u32 Tw = c_T[lane];
@@ -995,7 +1019,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             if (pf_at < ntok) q_pf = ld64u(src + wbase + (pf_at + lane < ntok ? c_pos[pf_at + lane] : 0u));
             u8* const my = c_stage + (ostart - mark);
             const u32 s_lo = ostart - off;
-            if (ready) lane_copy2(my, is_lit ? src + wbase + body : dst + s_lo, len);
+            if (ready && !(SNP_D_ABLATE & 1)) lane_copy2(my, is_lit ? src + wbase + body : dst + s_lo, len);
             u64 pend = ballot64(act && !ready);
             DPROF_ADD(0, 1);
             DPROF_ADD(1, ne);
@@ -1005,7 +1029,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 // second lane-parallel pass: sources inside the batch that no pending tag still has to write
                 bool blocked = off < len || s_lo < mark;                // pattern copies and sources straddling `mark`: finished in order
                 const bool mine = (pend >> lane) & 1ull;
-                if (pend & (pend - 1)) {
+                if ((SNP_D_ABLATE & 16) == 0 && (pend & (pend - 1))) {
                     c_busy[lane] = 0ull;
                     lanes_sync_lds();
                     if (mine) {
@@ -1023,7 +1047,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                         blocked = ((w0 & (mk << b0)) | (b0 ? (w1 & (mk >> (64u - b0))) : 0ull)) != 0ull;
                     }
                 }
-                const bool ready2 = mine && !blocked;
+                const bool ready2 = SNP_D_PASS2 && mine && !blocked;
                 lanes_sync_lds();
                 if (ready2) lane_copy2(my, c_stage + (s_lo - mark), len);
                 pend &= ~ballot64(ready2);
@@ -1032,6 +1056,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 // The rest in order, whole wave per tag, a byte per lane.  (This loop runs ~5 times per batch and is mostly scalar
                 // work -- the busiest unit of this kernel -- so the common case, a source inside the stage, is kept to one
                 // LDS read and one LDS write under one exec mask; LDS operations of a wave execute in order.)
+                if (SNP_D_ABLATE & 2) pend = 0;
                 while (pend) {
                     const u32 f = static_cast<u32>(__builtin_ctzll(pend));
                     pend &= pend - 1;
@@ -1061,10 +1086,12 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             // the whole run, coalesced
             lanes_sync_lds();
             u8* const g = dst + mark;
+            if (!(SNP_D_ABLATE & 4)) {
             for (u32 i = lane * 16; i + 16 <= span; i += SNP_WAVE * 16)
                 *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(c_stage + i);
             const u32 tail = span & ~15u;
             if (tail + lane < span) g[tail + lane] = c_stage[tail + lane];
+            }
             lanes_sync_lds();
             op += span;
             emitted += ne;

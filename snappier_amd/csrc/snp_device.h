@@ -45,7 +45,8 @@ __device__ __forceinline__ void wave_copy(u8* dst, const u8* src, u32 len, u32 l
         st32u(dst + done + lane * 4, ld32u(src + done + lane * 4));
         done += 256;
     }
-    for (u32 k = done + lane; k < len; k += 64) dst[k] = src[k];
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (u32 k = done + lane; k < len; k += 64) dst[k] = src[k];   // (< 256 bytes: at most four trips -- not worth the unrolled code)
 }
 
 // Framing mask  Crc32CAlgorithm.ApplyMask  (Snappier/Internal/Crc32CAlgorithm.cs:156-158)
