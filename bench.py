@@ -222,7 +222,7 @@ def main():
         # pass, same workload): per-block figures x blocks of this run.  See profiles/r01k_hbm_traffic.json for the caveat
         # on the gfx950 FETCH_SIZE calibration.
         pmc, pmc_file = {}, None
-        for cand in ("r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
+        for cand in ("r02p_hbm_traffic.json", "r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     pmc, pmc_file = json.load(f)["kernels"], cand
@@ -242,7 +242,7 @@ def main():
                     "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}
         lanes = nb >= 16384
         r_c = roof(ms_c, "k_compress_lanes" if lanes else "k_compress_win")
-        r_d = roof(ms_d, "k_decompress")
+        r_d = roof(ms_d, "k_decompress_chains" if "k_decompress_chains" in pmc else "k_decompress")
         if lanes:
             r_c["table_workspace_probe"] = {"chosen_ms": S.lib().snp_ctx_counter(cd.ctx.handle, 2) / 1e3,
                                             "candidates": S.lib().snp_ctx_counter(cd.ctx.handle, 3)}
@@ -266,7 +266,7 @@ def main():
                                     "configs[4]: 10 GiB of mixed-corpus 64 KiB blocks per GPU (80 GiB at 8 GPUs), ") +
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
-                       "layout": "decompress: one block per wavefront; compress: one fragment per lane with HBM tables (>= 16384 fragments), else one per wavefront with the table in LDS",
+                       "layout": "decompress: one block per wavefront (sub-chain tag parse over 2 KiB super-windows, 64 tags per execution batch staged in LDS); compress: one fragment per lane with HBM tables (>= 16384 fragments), else one per wavefront with the table in LDS",
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,

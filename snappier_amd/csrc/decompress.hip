@@ -231,7 +231,7 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 
 #ifndef SNP_D_ABLATE
 #define SNP_D_ABLATE 0      // TIMING-ONLY ablations of the sub-chain front end (the output is wrong): 1 no first-pass copies, 2 no serial finish,
-#endif                      // 4 no write-out, 8 no tag-byte load (decode garbage-free zeros), 16 no second pass
+#endif                      // 4 no write-out, 16 no second pass, 32 tag lists only (no batches)
 #ifndef SNP_D_PASS2
 #define SNP_D_PASS2 1       // sub-chain front end: second lane-parallel pass over the tags pass 1 could not take (0: they all finish one by one)
 #endif
@@ -964,7 +964,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     bits &= bits - 1u;
                 }
                 lanes_sync_lds();
-                emitted = 0;
+                emitted = (SNP_D_ABLATE & 32) ? ntok : 0;               // (ablation: build the tag lists only)
                 pf_at = ~0u;
                 DPROF_ADD(2, 1);                                        // super-windows
                 DPROF_ADD(9, __builtin_popcountll(active));             // lanes on the true chain
