@@ -27,9 +27,12 @@
 //      (offset < length) and literals > 64 B are done cooperatively by the whole wave.
 //   Anything irregular (an error, a tag or literal running past the input, the last < 72 input bytes) leaves the
 //   batch untouched and falls through to the serial loop, which owns the exact error semantics.
-// FRONT = 2 (default) parses windows the same way but appends their tags to a queue in LDS and executes 64 tags at a
-// time, so every vector-memory instruction is issued with all its lanes busy (a 64-byte window holds only ~21 tags).
-// FRAG = true decodes one 64 KiB fragment of a larger block from a tag start found by tag_index.hip.
+// FRONT = 2 parses windows the same way but appends their tags to a queue in LDS and executes 64 tags at a time, so
+// every vector-memory instruction is issued with all its lanes busy (a 64-byte window holds only ~21 tags).
+// FRONT = 3 (k_decompress_chains, the default for whole blocks) finds the tag starts of 2 KiB of input at once -- every
+// lane walks a chain of tags through its own 32 bytes, chains that meet are the same chain from there on -- and executes
+// 64 tags at a time straight from the resulting list (see the block comment at `if (FRONT == 3)`).
+// FRAG = true decodes one 64 KiB fragment of a larger block from a tag start found by tag_index.hip (FRONT 0 or 2).
 #include "snp_device.h"
 
 namespace {
@@ -806,13 +809,14 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
     // are the same chain from there on, and they meet within a few tags.  So:
     //   A   lane k walks region k from its first byte and records the positions it visits (32-bit mask V_k);
     //   A'  it walks on past the region's end until it lands on a position the owner of that region has visited (the
-    //       chains have merged: m_k, next lane nx_k), recording these overrun positions too (64-bit mask, two regions);
-    //   R   lane 0's chain is the true one (the super-window starts at a tag): following nx from lane 0 names the lanes
-    //       whose chains are true from their entry m_prev on; a chain that does not merge within two regions is walked
-    //       on by the whole wave, one tag at a time (rare);
+    //       chains have merged: m_k, next lane nx_k), recording these overrun positions too (a per-lane bitmap in LDS,
+    //       kCap = 128 bytes far at most);
+    //   R   lane 0's chain is the true one (the super-window starts at a tag): the lanes reachable from lane 0 along nx
+    //       are the lanes whose chains are true from their entry m_prev on (pointer doubling over the lanes); a true
+    //       chain that did not merge within kCap bytes is walked on by the whole wave, one tag at a time (rare);
     //   T   true tag starts = each active lane's V_k from its entry on, plus its overrun positions: a 2048-bit map, its
     //       popcount prefix numbers the tags, and the positions are written out as a u16 list (over the staged input).
-    // ~1 300 wave instructions per ~620 tags (html) instead of ~4 700, and 2 x ~15 dependent LDS reads instead of ~440.
+    // ~1 500 wave instructions per ~620 tags (html) instead of ~4 700, and ~40 dependent LDS round trips instead of ~440.
     // Tags then execute 64 at a time straight from that list: position -> tag bytes (one 8-byte load per lane) -> decode ->
     // prefix sum of the output lengths -> the staged batch of the queued front end (assembled in LDS, written out coalesced).
     // A batch ends before the first tag it cannot take (malformed, a literal > 64 bytes, the last 16 output bytes): a long
