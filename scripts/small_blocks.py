@@ -25,7 +25,7 @@ for bs in [int(a) for a in sys.argv[1:]] or [256, 1024, 4096, 16384, 65536]:
         return a.elapsed_time(b), r
     ms_c, (_, _, out_len, st) = timed(lambda: cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off))
     ms_d, (dlen, dst) = timed(lambda: cd.decompress(comp, comp_off, out_len, back, in_off, in_len))
-    ok = int((st != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and torch.equal(back, raw)
+    ok = int((st != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and torch.equal(back[: nb * bs], raw[: nb * bs])
     print(json.dumps({"block_bytes": bs, "blocks": nb, "ok": ok, "ratio": round(float(out_len.sum().item()) / total, 3),
                       "compress_GBps": round(total / ms_c / 1e6, 1), "decompress_GBps": round(total / ms_d / 1e6, 1),
                       "decode_layout": os.environ.get("SNAPPIER_HIP_DECODE", "chains")}), flush=True)

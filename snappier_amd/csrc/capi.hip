@@ -66,10 +66,10 @@ struct snp_ctx {
     int compress_mode = 0;   // 0 auto by batch size, 2 fragment-per-lane with HBM tables (compress_lanes.hip), 3 fragment-per-wavefront
                              // with the table in LDS, multi-token windows (compress_win.hip)
     int win_np = 1;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2; 2 measured slower)
-    u32 small_max = 512;     // blocks declaring at most this many bytes are decoded one per LANE (decompress_small.hip); 0 = never.
-                             // Measured (profiles/r02d_small_blocks.jsonl): the lane kernel runs at ~190 GB/s whatever the block size
-                             // (uncoalesced 16-byte accesses: the same transaction-rate wall as the lane compressor), the wave kernel at
-                             // 126 / 251 / 427 GB/s for 256 B / 1 KiB / 4 KiB blocks: the crossover is between 512 B and 1 KiB.
+    u32 small_max = 384;     // blocks declaring at most this many bytes are decoded one per LANE (decompress_small.hip); 0 = never.
+                             // Measured (profiles/r02s_small_block_crossover.jsonl): the lane kernel runs at ~190-200 GB/s whatever the block
+                             // size (uncoalesced 16-byte accesses: the same transaction-rate wall as the lane compressor), the wave kernel
+                             // (sub-chain front end) at 148 / 166 / 187 / 208 / 226 / 327 GB/s for 256 / 320 / 384 / 448 / 512 / 1024-byte blocks.
     u32 small_min_blocks = 4096;   // ... in batches of at least this many blocks
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
     DevBuf in, out, meta, work, tables, scan, small;

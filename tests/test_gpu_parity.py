@@ -431,6 +431,42 @@ def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     assert dst.cpu().tolist() == [O.decompress_status(b, c) for b, c in zip(blobs, caps)]
 
 
+@pytest.mark.parametrize("decode", ["chains", "queued", "batched", "serial"])
+def test_streams_built_against_the_sub_chain_decoder(decode, monkeypatch):
+    """Legal Snappy that no 64 KiB-fragment compressor emits, chosen so that the guessed chains of the sub-chain front end
+    (decompress.hip, FRONT = 3) rarely or never land on a tag start: 5- and 7-byte tag periods, literal bodies made of
+    long-literal tag bytes, copy-2 offsets that read as long literals.  Output and status must equal the oracle's through
+    every front end, also when such streams are truncated or their capacity is one byte short."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("adversarial_streams", os.path.join(ROOT, "scripts", "adversarial_streams.py"))
+    A = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(A)
+    monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    blobs, caps = [], []
+    for kind in ("copy4_len4_period5", "copy4_len64_period5", "literals_of_f4", "copy2_offsets_f4f4", "period7_mix"):
+        s = A.build(kind)
+        for cut, cap in ((len(s), 65536), (len(s), 65535), (len(s) - 1, 65536), (len(s) // 2, 65536), (2100, 65536)):
+            blobs.append(s[:cut])
+            caps.append(cap)
+    data = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    in_len = np.array([len(b) for b in blobs], dtype=np.int32)
+    in_off = np.concatenate([[0], np.cumsum(in_len[:-1])]).astype(np.int64)
+    out_cap = np.array(caps, dtype=np.int32)
+    out_off = (np.arange(len(blobs), dtype=np.int64) * 65600)
+    out = torch.zeros(len(blobs) * 65600, dtype=torch.uint8, device="cuda")
+    dlen, dst = cd.decompress(to_dev(data), to_dev(in_off), to_dev(in_len), out, to_dev(out_off), to_dev(out_cap))
+    torch.cuda.synchronize()
+    dlen, dst, h_out = dlen.cpu().numpy(), dst.cpu().numpy(), out.cpu().numpy()
+    want_st = [O.decompress_status(b, c) for b, c in zip(blobs, caps)]
+    assert dst.tolist() == want_st
+    for i, (b, c) in enumerate(zip(blobs, caps)):
+        if want_st[i] == 0:
+            ref = O.decompress(b, c)
+            assert dlen[i] == len(ref)
+            assert_same(f"{decode} stream {i}", h_out[out_off[i]: out_off[i] + dlen[i]].tobytes(), ref)
+
+
 @pytest.mark.parametrize("bs", [64, 256, 1000, 4096])
 def test_many_small_blocks_roundtrip_and_parity(bs):               # SURVEY 8(f4); SnappyStreamTests.cs:145-192 pattern
     """Batches of small blocks take the block-per-lane decoder and the lane compressor with small tables: every block
