@@ -53,6 +53,12 @@ def build(kind, total=65536):
     elif kind == "literals_of_f4":              # literal bodies of 0xF4: every chain that starts inside one reads a 3-byte-length literal
         while produced + 60 <= total:
             emit(lit(bytes([0xF4]) * 60), 60)
+    elif kind == "literals_of_ff_period61":     # 60-byte literals of 0xFF (as a tag: copy-4, 5 bytes): chains inside the bodies step by 5 and meet a
+        while produced + 60 <= total:           # tag start (every 61 bytes) only after ~300 bytes: the true chain does NOT merge within the cap
+            emit(lit(bytes([0xFF]) * 60), 60)
+    elif kind == "literals_of_14_period7":      # every byte 0x14 = "literal of 6": all seven phases are self-consistent chains, only every
+        while produced + 6 <= total:            # seventh lane starts on the true one (224 bytes apart): the fallback runs in every super-window
+            emit(lit(bytes([0x14]) * 6), 6)
     elif kind == "copy2_offsets_f4f4":          # copy-2 tags whose offset bytes are long-literal tag bytes (offset 0xF4F4 needs 62 KiB behind it: use a literal run first)
         emit(lit(bytes(range(256)) * 250), 64000)
         while produced + 4 <= total:
@@ -67,6 +73,10 @@ def build(kind, total=65536):
     return varint(total) + bytes(out)
 
 
+KINDS = ("copy4_len4_period5", "copy4_len64_period5", "literals_of_f4", "literals_of_ff_period61", "literals_of_14_period7",
+         "copy2_offsets_f4f4", "period7_mix")
+
+
 def main():
     import torch
     import snappier_amd as S
@@ -74,7 +84,7 @@ def main():
     from oracle import pyoracle as O
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
     mode = os.environ.get("SNAPPIER_HIP_DECODE", "chains")
-    for kind in ("copy4_len4_period5", "copy4_len64_period5", "literals_of_f4", "copy2_offsets_f4f4", "period7_mix"):
+    for kind in KINDS:
         stream = build(kind)
         want = O.decompress(stream)
         assert len(want) == 65536

@@ -444,7 +444,7 @@ def test_streams_built_against_the_sub_chain_decoder(decode, monkeypatch):
     monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
     blobs, caps = [], []
-    for kind in ("copy4_len4_period5", "copy4_len64_period5", "literals_of_f4", "copy2_offsets_f4f4", "period7_mix"):
+    for kind in A.KINDS:
         s = A.build(kind)
         for cut, cap in ((len(s), 65536), (len(s), 65535), (len(s) - 1, 65536), (len(s) // 2, 65536), (2100, 65536)):
             blobs.append(s[:cut])
