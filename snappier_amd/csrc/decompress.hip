@@ -921,29 +921,29 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     consumed = ends ? read_lane(m, static_cast<u32>(__builtin_ctzll(ends))) : 0u;
                 }
                 if (ballot64(((active >> lane) & 1ull) && nx == 65u)) {
-                // a chain on the true path did not merge within kCap bytes (rare: ~2 per block on html): follow the path lane by
-                // lane on the scalar unit instead, walking such a chain on, whole wave, until it merges or leaves
-                active = 0;
-                entry = 0;
-                for (u32 k = 0, e = 0;;) {
-                    active |= 1ull << k;
-                    entry = lane == k ? e : entry;
-                    u32 mk = read_lane(m, k), nk = read_lane(nx, k);
-                    if (nk == 65u) {
-                        DPROF_ADD(7, 1);
-                        nk = 64u;
-                        while (mk < L) {
-                            const u32 v = bcast_first(c_V[mk >> 5]);
-                            if ((v >> (mk & 31u)) & 1u) { nk = mk >> 5; break; }
-                            if (lane == 0) atomicOr(&c_T[mk >> 5], 1u << (mk & 31u));
-                            mk += bcast_first(tag_advance_staged(c_in + mk));
-                            DPROF_ADD(8, 1);
+                    // a chain on the true path did not merge within kCap bytes (rare: ~2 per block on html): follow the path lane by
+                    // lane on the scalar unit instead, walking such a chain on, whole wave, until it merges or leaves
+                    active = 0;
+                    entry = 0;
+                    for (u32 k = 0, e = 0;;) {
+                        active |= 1ull << k;
+                        entry = lane == k ? e : entry;
+                        u32 mk = read_lane(m, k), nk = read_lane(nx, k);
+                        if (nk == 65u) {
+                            DPROF_ADD(7, 1);
+                            nk = 64u;
+                            while (mk < L) {
+                                const u32 v = bcast_first(c_V[mk >> 5]);
+                                if ((v >> (mk & 31u)) & 1u) { nk = mk >> 5; break; }
+                                if (lane == 0) atomicOr(&c_T[mk >> 5], 1u << (mk & 31u));
+                                mk += bcast_first(tag_advance_staged(c_in + mk));
+                                DPROF_ADD(8, 1);
+                            }
                         }
+                        if (nk >= 64u) { consumed = mk; break; }
+                        e = mk;
+                        k = nk;
                     }
-                    if (nk >= 64u) { consumed = mk; break; }
-                    e = mk;
-                    k = nk;
-                }
                 }
                 // T: the true tag starts
                 if ((active >> lane) & 1ull) {
