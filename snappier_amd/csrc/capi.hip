@@ -21,7 +21,10 @@ hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
                                    hipStream_t);
 hipError_t snp_launch_decompress_small(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*,
-                                       u32, hipStream_t);
+                                       u32, hipStream_t, u32*, u32*, u32);
+hipError_t snp_launch_sample_caps(const u32*, u32, u32, u32*, hipStream_t);
+hipError_t snp_launch_decompress_list(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*, int,
+                                      hipStream_t, const u32*, u32*, u32, u32);
 hipError_t snp_launch_compress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, void*,
                                      u32*, hipStream_t);
 size_t snp_compress_lanes_workspace(u32);
@@ -71,8 +74,11 @@ struct snp_ctx {
                              // size (uncoalesced 16-byte accesses: the same transaction-rate wall as the lane compressor), the wave kernel
                              // (sub-chain front end) at 148 / 166 / 187 / 208 / 226 / 327 GB/s for 256 / 320 / 384 / 448 / 512 / 1024-byte blocks.
     u32 small_min_blocks = 4096;   // ... in batches of at least this many blocks
+    bool small_lanes = false;      // SNAPPIER_HIP_SMALL=lanes: the block-per-lane kernel instead of a team of lanes per block
+    bool redo_grid = false, redo_list = false;   // SNAPPIER_HIP_REDO=grid|list pins how the pre-pass's leftovers are decoded (default: by how the previous batch went)
+    u32 small_team_log = 0;        // SNAPPIER_HIP_SMALL=team4|team8|team16: lanes per block (0 = the kernel's default)
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
-    DevBuf in, out, meta, work, tables, scan, small;
+    DevBuf in, out, meta, work, tables, scan, small, redo;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
     uint64_t counters[4] = {0, 0, 0, 0};   // snp_ctx_counter
     std::string err;
@@ -84,15 +90,91 @@ struct snp_ctx {
         // Large batches first go through the block-per-lane kernel, which finishes every clean block of <= small_max bytes
         // and marks the rest; the wave kernel then takes exactly those (all of them when every block is a 64 KiB block: the
         // first launch is then 163 840 lanes that read two words each).
-        int redo = 0;
         if (small_max && nblocks >= small_min_blocks && decode_layout == 0) {
-            if (!check(snp_launch_decompress_small(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
-                                                   chunk_type, small_max, stream), "decompress (small blocks) launch"))
-                return false;
-            redo = 16;
+            // Small clean blocks are finished by a pre-pass (decompress_small.hip: a lane or a team of lanes per block), which
+            // appends the blocks it leaves over to a list; a chip-full of persistent wavefronts then decodes the list
+            // (decompress.hip, k_decompress_chains_list: no launch per finished block -- 4 M blocks of 256 bytes 4.7 -> 3.3 ms, 64-byte
+            // blocks 180 -> 420 GB/s).  For a batch of LARGE blocks all of that is overhead (a pre-pass that rejects 2 M blocks of
+            // 512 bytes costs as much as decoding them, and the list kernel is 5-9 % slower than one workgroup per block), and what
+            // a batch is like is known only on the device.  So the context remembers the previous batch: its leftover count, or a
+            // sample of its capacities, comes back with an asynchronous copy that is read here only once it has landed, and this
+            // batch is assumed to be alike (first batch: pre-pass).  The results are the same either way; SNAPPIER_HIP_REDO pins it.
+            const u32 sub_cap = nblocks / 64 + 128;                     // a sub-list holds the leftovers of every 64th wavefront of the pre-pass
+            if (!ensure(redo, (static_cast<size_t>(sub_cap) * 64 + 128) * 4, "hipMalloc(redo list)")) return false;
+            u32* const ctl = static_cast<u32*>(redo.p);                 // [0..63] sub-list lengths, [64] ticket, [65..67] size sample
+            u32* const list = ctl + 128;
+            if (hint && hint_ev && hint_pending && hipEventQuery(hint_ev) == hipSuccess) {
+                hint_pending = false;
+                if (hint_from_prepass) {
+                    u64 left = 0;
+                    for (int k = 0; k < 64; ++k) left += hint[k];
+                    hint_mostly_large = left * 2 > hint_blocks;
+                } else if (hint[67]) {
+                    hint_mostly_large = static_cast<u64>(hint[65]) * 2 < hint[67];
+                }
+                if (hint[67]) hint_mean_cap = static_cast<u32>((static_cast<u64>(hint[66]) << 4) / hint[67]);
+            } else {
+                (void)hipGetLastError();
+            }
+            const bool chains = (fenced & 8) != 0;
+            const bool prepass = redo_list || !chains || (!redo_grid && !hint_mostly_large);
+            if (!check(hipMemsetAsync(ctl, 0, 68 * 4, stream), "memset(redo list)")) return false;
+            bool ok;
+            if (prepass) {
+                // lanes per block, by the mean block size of the previous batch (profiles/r02t_small_block_layouts.jsonl:
+                // 64 B: one lane 425 GB/s, 4 lanes 387; 128 B: 4 lanes 340, 8 lanes 313; 256 B: 8 lanes 316, 16 lanes 246; 384-512 B: 16 lanes 244)
+                const u32 lim = small_max > 512u ? 512u : small_max;
+                u32 lay;
+                if (small_lanes) lay = (small_max & 0x0fffffffu) | 0x80000000u;
+                else if (small_team_log) lay = lim | (small_team_log << 28);
+                else if (hint_mean_cap <= 96) lay = lim | 0x80000000u;
+                else lay = lim | ((hint_mean_cap <= 192 ? 2u : hint_mean_cap <= 320 ? 3u : 4u) << 28);
+                if (!check(snp_launch_decompress_small(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
+                                                       chunk_type, lay, stream, chains ? list : nullptr, ctl, sub_cap), "decompress (small blocks) launch"))
+                    return false;
+                if (chains)
+                    ok = check(snp_launch_decompress_list(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status, chunk_type,
+                                                          fenced | ((dec_lds / 256) << 8), stream, list, ctl, persistent_waves(), sub_cap), "decompress (list) launch");
+                else
+                    ok = check(snp_launch_decompress(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
+                                                     chunk_type, fenced | 16 | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch");
+            } else {
+                ok = check(snp_launch_decompress(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
+                                                 chunk_type, fenced | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch") &&
+                     check(snp_launch_sample_caps(out_cap, nblocks, small_max, ctl, stream), "sample launch");
+            }
+            if (ok && hint_ready() && !hint_pending) {                   // how this batch went, for the next one
+                hint_blocks = nblocks;
+                hint_from_prepass = prepass;
+                if (hipMemcpyAsync(hint, ctl, 68 * 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipEventRecord(hint_ev, stream) == hipSuccess)
+                    hint_pending = true;
+                else
+                    (void)hipGetLastError();
+            }
+            return ok;
         }
         return check(snp_launch_decompress(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
-                                           chunk_type, fenced | redo | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch");
+                                           chunk_type, fenced | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch");
+    }
+    u32* hint = nullptr;                                 // pinned: the previous batch's list length
+    hipEvent_t hint_ev = nullptr;
+    bool hint_pending = false, hint_mostly_large = false, hint_from_prepass = false;
+    u32 hint_blocks = 0, hint_mean_cap = 256;            // (no history yet: assume 256-byte blocks)
+    bool hint_ready()
+    {
+        if (!hint && hipHostMalloc(reinterpret_cast<void**>(&hint), 68 * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hint = nullptr; return false; }
+        if (!hint_ev && hipEventCreateWithFlags(&hint_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); hint_ev = nullptr; return false; }
+        return true;
+    }
+    u32 n_waves = 0;
+    u32 persistent_waves()                               // one chip-full of 64-thread workgroups at 8 wavefronts per SIMD
+    {
+        if (!n_waves) {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+            n_waves = static_cast<u32>(cus) * 32u;
+        }
+        return n_waves;
     }
 
     // One launch of the compressor over nblocks fragments, picking the layout (see compress_lanes.hip).
@@ -292,6 +374,12 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->frame_scan = (fs && strcmp(fs, "serial") == 0) ? 1 : 0;
     const char* sm = getenv("SNAPPIER_HIP_SMALL_MAX");
     if (sm) c->small_max = static_cast<u32>(strtoul(sm, nullptr, 10));
+    const char* sl = getenv("SNAPPIER_HIP_SMALL");
+    c->small_lanes = sl && strcmp(sl, "lanes") == 0;
+    c->small_team_log = (sl && strcmp(sl, "team4") == 0) ? 2 : (sl && strcmp(sl, "team8") == 0) ? 3 : (sl && strcmp(sl, "team16") == 0) ? 4 : 0;
+    const char* rg = getenv("SNAPPIER_HIP_REDO");
+    c->redo_grid = rg && strcmp(rg, "grid") == 0;
+    c->redo_list = rg && strcmp(rg, "list") == 0;
     const char* sn = getenv("SNAPPIER_HIP_SMALL_MIN");
     if (sn) c->small_min_blocks = static_cast<u32>(strtoul(sn, nullptr, 10));
     const char* wm = getenv("SNAPPIER_HIP_WIN_MAX");
@@ -314,9 +402,11 @@ void snp_ctx_destroy(snp_ctx* c)
     {
         DevGuard dg(c);
         (void)hipStreamSynchronize(c->stream);
-        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan, &c->small})
+        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan, &c->small, &c->redo})
             if (b->p) (void)hipFree(b->p);
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+        if (c->hint_ev) (void)hipEventDestroy(c->hint_ev);
+        if (c->hint) (void)hipHostFree(c->hint);
         if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
         for (auto& e : c->copy_ev) if (e) (void)hipEventDestroy(e);
         if (c->own_stream) (void)hipStreamDestroy(c->stream);

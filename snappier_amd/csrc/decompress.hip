@@ -306,10 +306,9 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                                                  const u64* __restrict__ out_off,
                                                  const u32* __restrict__ out_cap, u32* __restrict__ out_len,
                                                  i32* __restrict__ status, const u8* __restrict__ chunk_type,
-                                                 const u32* __restrict__ frag_skip, int redo_only)
+                                                 const u32* __restrict__ frag_skip, int redo_only, const u32 b)
 {
     static_assert(!FRAG || (FRONT != 1 && FRONT != 3), "fragment mode: serial loop or queued front end");
-    const u32 b = blockIdx.x;
     if (b >= nblocks) return;
     if (redo_only && status[b] != -1) return;            // decompress_small.hip finished this block (it marks the others -1)
     const u32 lane = lane_id();
@@ -1191,7 +1190,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
 template <bool FENCED, int FRONT, bool FRAG>
 __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(SNP_D_PARAMS)
 {
-    decompress_block<FENCED, FRONT, FRAG>(SNP_D_ARGS);
+    decompress_block<FENCED, FRONT, FRAG>(SNP_D_ARGS, blockIdx.x);
 }
 
 // The sub-chain front end needs 68 VGPRs left to itself; at 64 (two spilled) it runs eight wavefronts per SIMD instead of
@@ -1202,7 +1201,40 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(SNP_D_PARAMS)
 template <bool FENCED>
 __global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_CHAIN_WAVES, SNP_D_CHAIN_WAVES))) void k_decompress_chains(SNP_D_PARAMS)
 {
-    decompress_block<FENCED, 3, false>(SNP_D_ARGS);
+    decompress_block<FENCED, 3, false>(SNP_D_ARGS, blockIdx.x);
+}
+
+// The same over a LIST of blocks: the blocks the small-block pre-pass (decompress_small.hip) did not finish, which it appended
+// to `list` (ctl[0] = how many).  Persistent: the grid is one chip-full of wavefronts and each takes the next list entry with a
+// ticket (ctl[1]) until the list is empty -- when the pre-pass finished everything (millions of small blocks) this launch costs
+// microseconds instead of one empty workgroup per block (0.87 of 4.7 ms for 4 M blocks of 256 bytes), and when it finished
+// nothing (64 KiB blocks) the wavefronts simply decode ~20 blocks each, balanced by the tickets.
+template <bool FENCED>
+__global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_CHAIN_WAVES, SNP_D_CHAIN_WAVES))) void k_decompress_chains_list(
+    SNP_D_PARAMS, const u32* __restrict__ list, u32* __restrict__ ctl, u32 sub_cap)
+{
+    // 64 sub-lists (decompress_small.hip, append_redo): lane s holds the number of entries before sub-list s.
+    // (Starting the wavefronts a few microseconds apart, as a grid launch would, changes nothing: measured.)
+    const u32 lane = lane_id();
+    const u32 mine = __hip_atomic_load(&ctl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 incl = wave_inclusive_scan(mine);
+    const u32 count = read_lane(incl, 63);
+    // tickets are taken several at a time: one counter for 2 M small blocks was the whole run time (12 ns per atomic on one
+    // address: 512-byte blocks 40 GB/s); a wavefront now takes ~1/8 of its fair share per atomic, at most 64
+    const u32 grab = min(max(count / (gridDim.x * 8u), 1u), 64u);
+    for (;;) {
+        u32 first = 0;
+        if (lane == 0) first = atomicAdd(&ctl[64], grab);
+        first = bcast_first(first);
+        if (first >= count) break;
+        const u32 last = min(first + grab, count);
+        for (u32 i = first; i < last; ++i) {
+            const u32 sub = static_cast<u32>(__builtin_popcountll(ballot64(incl <= i)));   // the sub-list ticket i falls into
+            const u32 before = read_lane(incl - mine, sub);
+            decompress_block<FENCED, 3, false>(SNP_D_ARGS, list[static_cast<u64>(sub) * sub_cap + (i - before)]);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the next block reuses the LDS arrays)
+        }
+    }
 }
 
 }  // namespace
@@ -1218,6 +1250,24 @@ extern "C" int snp_debug_read_dprof(unsigned long long* out16, int reset)
     return static_cast<int>(e);
 }
 #endif
+
+// The blocks of `list` (see k_decompress_chains_list): waves = wavefronts to launch (one chip-full), mode bit 0 = FENCED.
+extern "C" hipError_t snp_launch_decompress_list(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
+                                                 const u64* out_off, const u32* out_cap, u32* out_len, i32* status,
+                                                 const u8* chunk_type, int mode, hipStream_t stream, const u32* list, u32* ctl,
+                                                 u32 waves, u32 sub_cap)
+{
+    if (nblocks == 0) return hipSuccess;
+    const unsigned lds_bytes = static_cast<unsigned>(mode >> 8) * 256u;
+    const u32* const no_skip = nullptr;
+    if (mode & 1)
+        hipLaunchKernelGGL((k_decompress_chains_list<true>), dim3(waves), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks,
+                           out, out_off, out_cap, out_len, status, chunk_type, no_skip, 0, list, ctl, sub_cap);
+    else
+        hipLaunchKernelGGL((k_decompress_chains_list<false>), dim3(waves), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks,
+                           out, out_off, out_cap, out_len, status, chunk_type, no_skip, 0, list, ctl, sub_cap);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                             const u64* out_off, const u32* out_cap, u32* out_len, i32* status,

@@ -406,6 +406,7 @@ def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     if decode == "small":       # block-per-lane kernel first, for every block size; what it cannot finish goes to the wave kernel
         monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
         monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "65536")
+        monkeypatch.setenv("SNAPPIER_HIP_REDO", "list")           # always the pre-pass + list kernel, whatever the previous batch was like
     else:
         monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
