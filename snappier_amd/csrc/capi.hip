@@ -121,13 +121,14 @@ struct snp_ctx {
             if (!check(hipMemsetAsync(ctl, 0, 68 * 4, stream), "memset(redo list)")) return false;
             bool ok;
             if (prepass) {
-                // lanes per block, by the mean block size of the previous batch (profiles/r02t_small_block_layouts.jsonl:
-                // 64 B: one lane 425 GB/s, 4 lanes 387; 128 B: 4 lanes 340, 8 lanes 313; 256 B: 8 lanes 316, 16 lanes 246; 384-512 B: 16 lanes 244)
+                // lanes per block, by the mean block size of the previous batch (profiles/r02t_small_block_layouts.jsonl, GB/s:
+                // 32 B: one lane 558, 4 lanes 395; 64 B: 418 / 444; 128 B: 4 lanes 435, 8 lanes 340; 256 B: 4 lanes 302, 8 lanes 351,
+                // 16 lanes 235; 384-512 B: 16 lanes 231, 8 lanes 211-216)
                 const u32 lim = small_max > 512u ? 512u : small_max;
                 u32 lay;
                 if (small_lanes) lay = (small_max & 0x0fffffffu) | 0x80000000u;
                 else if (small_team_log) lay = lim | (small_team_log << 28);
-                else if (hint_mean_cap <= 96) lay = lim | 0x80000000u;
+                else if (hint_mean_cap <= 48) lay = lim | 0x80000000u;
                 else lay = lim | ((hint_mean_cap <= 192 ? 2u : hint_mean_cap <= 320 ? 3u : 4u) << 28);
                 if (!check(snp_launch_decompress_small(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
                                                        chunk_type, lay, stream, chains ? list : nullptr, ctl, sub_cap), "decompress (small blocks) launch"))

@@ -277,13 +277,29 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
             u32 from = type == 0 ? body : kOut + op - off;              // slot offset the tag's first byte comes from
             u32 dist = type == 0 ? 0xffffu : off;
             const u32 to = kOut + op;
-            for (u32 done = 0; done < len;) {
-                const u32 w = min(min(dist, TEAM), len - done);
-                if (tl < w) tin[to + done + tl] = tin[from + done + tl];
-                done += w;
-                if (dist <= done && dist < TEAM) {                      // a pattern: twice the distance is the same bytes
-                    from -= dist;
-                    dist *= 2;
+            if (dist >= len) {
+                // the tag reads nothing it writes (every literal, most copies): its steps are independent -- four in flight at a
+                // time, so that a 30-byte literal costs one LDS round trip instead of four
+                for (u32 k0 = tl; k0 < len; k0 += 4 * TEAM) {
+                    const u32 k1 = k0 + TEAM, k2 = k1 + TEAM, k3 = k2 + TEAM;
+                    u8 v0 = tin[from + k0], v1 = 0, v2 = 0, v3 = 0;
+                    if (k1 < len) v1 = tin[from + k1];
+                    if (k2 < len) v2 = tin[from + k2];
+                    if (k3 < len) v3 = tin[from + k3];
+                    tin[to + k0] = v0;
+                    if (k1 < len) tin[to + k1] = v1;
+                    if (k2 < len) tin[to + k2] = v2;
+                    if (k3 < len) tin[to + k3] = v3;
+                }
+            } else {
+                for (u32 done = 0; done < len;) {
+                    const u32 w = min(min(dist, TEAM), len - done);
+                    if (tl < w) tin[to + done + tl] = tin[from + done + tl];
+                    done += w;
+                    if (dist <= done && dist < TEAM) {                  // a pattern: twice the distance is the same bytes
+                        from -= dist;
+                        dist *= 2;
+                    }
                 }
             }
             ip = type == 0 ? body + len : body;
