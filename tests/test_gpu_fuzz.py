@@ -145,9 +145,11 @@ def corrupt(rng: np.random.Generator, z: np.ndarray) -> np.ndarray:
     return z
 
 
-@pytest.mark.parametrize("decode", ["queued", "chains", "batched", "serial", "small"])
+@pytest.mark.parametrize("decode", ["queued", "chains", "batched", "serial", "small", "small-lanes", "small-team4", "small-team16"])
 def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatch):
-    if decode == "small":       # every block first goes through the block-per-lane kernel (decompress_small.hip), whatever its size
+    if decode.startswith("small"):   # every block first goes through the small-block pre-pass (decompress_small.hip: 8 lanes per block, or the named layout)
+        if "-" in decode:
+            monkeypatch.setenv("SNAPPIER_HIP_SMALL", decode.split("-")[1])
         monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
         monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "65536")
         monkeypatch.setenv("SNAPPIER_HIP_REDO", "list")           # always the pre-pass + list kernel, whatever the previous batch was like
@@ -182,3 +184,57 @@ def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatc
         assert ok.size > BLOCKS // 10 and ok.size < BLOCKS    # the corruptions produce both outcomes
     log_session(test="corrupted_streams_status_and_bytes_equal_oracle", decode=decode, rounds=ROUNDS, blocks_per_round=BLOCKS,
                 blocks_compared=ROUNDS * BLOCKS, seeds=[777 + r for r in range(ROUNDS)], result="all statuses and bytes equal")
+
+
+@pytest.mark.parametrize("layout", ["lanes", "team4", "team8", "team16"])
+def test_fuzz_small_blocks_corrupted_streams_equal_oracle(layout, monkeypatch):
+    """The small-block pre-pass (decompress_small.hip) on what it is for: thousands of blocks of 1 .. 512 bytes, two thirds of them
+    corrupted, through every layout (a lane, or a team of 4 / 8 / 16 lanes, per block); leftovers go to the list kernel.  Status,
+    length and bytes of every block must equal the oracle's."""
+    monkeypatch.setenv("SNAPPIER_HIP_SMALL", layout)
+    monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
+    monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "512")
+    monkeypatch.setenv("SNAPPIER_HIP_REDO", "list")
+    text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt") + read_testdata("geo.protodata"), dtype=np.uint8)
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    nb = 4 * BLOCKS
+    for r in range(ROUNDS):
+        rng = np.random.default_rng(4242 + r)
+        blocks = []
+        for _ in range(nb):
+            n = int(rng.integers(1, 513))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                blocks.append(rng.integers(0, 256, n, dtype=np.uint8))
+            elif kind == 1:                                    # a short pattern repeated: overlapping copies with small offsets
+                p = rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)
+                blocks.append(np.tile(p, n // len(p) + 1)[:n])
+            else:
+                s = int(rng.integers(0, len(text) - n))
+                blocks.append(text[s: s + n].copy())
+        data, off, lens = batch_of(blocks)
+        comp, c_off, c_len, _ = O.compress_batch(data, off.astype(np.uint64), lens.astype(np.uint32), O.HASH_CRC32C, THREADS)
+        streams = []
+        for b in range(nb):
+            z = comp[int(c_off[b]): int(c_off[b]) + int(c_len[b])]
+            streams.append(corrupt(rng, z) if rng.integers(0, 3) else z.copy())
+        sdata, s_off, s_len = batch_of(streams)
+        caps = np.array([len(b) if rng.integers(0, 8) else max(1, len(b) - int(rng.integers(0, 3))) for b in blocks], dtype=np.int32)
+        out_off = np.zeros(nb, dtype=np.int64)
+        out_off[1:] = np.cumsum(caps[:-1].astype(np.int64) + 64)
+        total = int(out_off[-1]) + int(caps[-1]) + 64
+        ref, ref_len, ref_st = O.decompress_batch(sdata, s_off.astype(np.uint64), s_len.astype(np.uint32), out_off.astype(np.uint64),
+                                                  caps.astype(np.uint32), total, THREADS)
+        out = torch.zeros(total, dtype=torch.uint8, device="cuda")
+        dlen, dst = cd.decompress(dev(sdata), dev(s_off), dev(s_len), out, dev(out_off), dev(caps))
+        torch.cuda.synchronize()
+        dlen, dst, out = dlen.cpu().numpy(), dst.cpu().numpy(), out.cpu().numpy()
+        bad = np.nonzero(dst != ref_st)[0]
+        assert bad.size == 0, f"round {r} {layout}: status differs at blocks {bad[:8]}: got {dst[bad[:8]]} want {ref_st[bad[:8]]}"
+        ok = np.nonzero(ref_st == 0)[0]
+        assert (dlen[ok] == ref_len[ok]).all()
+        idx = np.concatenate([np.arange(out_off[b], out_off[b] + ref_len[b]) for b in ok])
+        assert np.array_equal(out[idx], ref[idx]), f"round {r} {layout}: bytes differ"
+        assert ok.size > nb // 10 and ok.size < nb
+    log_session(test="small_blocks_corrupted_streams_equal_oracle", layout=layout, rounds=ROUNDS, blocks_per_round=nb,
+                blocks_compared=ROUNDS * nb, seeds=[4242 + r for r in range(ROUNDS)], result="all statuses, lengths and bytes equal")
