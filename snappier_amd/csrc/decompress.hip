@@ -1222,11 +1222,9 @@ __global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_
     // tickets are taken several at a time: one counter for 2 M small blocks was the whole run time (12 ns per atomic on one
     // address: 512-byte blocks 40 GB/s); a wavefront now takes ~1/8 of its fair share per atomic, at most 64
     const u32 grab = min(max(count / (gridDim.x * 8u), 1u), 64u);
-    for (;;) {
-        u32 first = 0;
-        if (lane == 0) first = atomicAdd(&ctl[64], grab);
-        first = bcast_first(first);
-        if (first >= count) break;
+    // (a wavefront's first tickets are its by position; only the later ones come from the counter: 8 192 wavefronts hitting one
+    // address at once took 82 us, the whole cost of an empty list)
+    for (u32 first = blockIdx.x * grab; first < count;) {
         const u32 last = min(first + grab, count);
         for (u32 i = first; i < last; ++i) {
             const u32 sub = static_cast<u32>(__builtin_popcountll(ballot64(incl <= i)));   // the sub-list ticket i falls into
@@ -1234,6 +1232,9 @@ __global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_
             decompress_block<FENCED, 3, false>(SNP_D_ARGS, list[static_cast<u64>(sub) * sub_cap + (i - before)]);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the next block reuses the LDS arrays)
         }
+        u32 next = 0;
+        if (lane == 0) next = atomicAdd(&ctl[64], grab);
+        first = gridDim.x * grab + bcast_first(next);
     }
 }
 
