@@ -253,11 +253,14 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
             bad = !done || expected > cap;
         }
         const bool run = now && !bad;
+        // (the three dwords of the NEXT tag are requested before this tag's bytes are moved: one LDS round trip less per tag)
+        u32 d0 = 0, d1 = 0, d2 = 0;
+        if (run) {
+            const u32 a = ip & ~3u;
+            d0 = *reinterpret_cast<const u32*>(tin + a), d1 = *reinterpret_cast<const u32*>(tin + a + 4), d2 = *reinterpret_cast<const u32*>(tin + a + 8);
+        }
         while (run && op < expected) {                                  // SnappyDecompressor.DecompressAllTags :234-341, one tag per trip
             if (ip >= n) { bad = true; break; }                         // input ends early: decompress.hip reports it
-            const u32 a = ip & ~3u;
-            const u32 d0 = *reinterpret_cast<const u32*>(tin + a), d1 = *reinterpret_cast<const u32*>(tin + a + 4),
-                      d2 = *reinterpret_cast<const u32*>(tin + a + 8);
             const u32 lo = __builtin_amdgcn_alignbyte(d1, d0, ip & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, ip & 3u);
             const u32 c = lo & 0xffu;
             const u32 type = c & 3u;
@@ -273,6 +276,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
             else { len = hi6 + 1; off = trailer; }
             // irregular -> leave it all to decompress.hip (TOO_LONG / BAD_OFFSET / partial literal); len = 0 is a 2^32-byte literal
             if (len - 1u >= expected - op || (type == 0 ? (len > n - body) : (off == 0 || off > op))) { bad = true; break; }
+            const u32 nip = type == 0 ? body + len : body;
+            {
+                const u32 a = nip & ~3u;                                // (nip <= n: inside the slot's slack)
+                d0 = *reinterpret_cast<const u32*>(tin + a), d1 = *reinterpret_cast<const u32*>(tin + a + 4), d2 = *reinterpret_cast<const u32*>(tin + a + 8);
+            }
             // literal (Append :568-589): source = the input;  copy (AppendFromSelf :591-611): source = dist bytes back in the output
             u32 from = type == 0 ? body : kOut + op - off;              // slot offset the tag's first byte comes from
             u32 dist = type == 0 ? 0xffffu : off;
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
                     }
                 }
             }
-            ip = type == 0 ? body + len : body;
+            ip = nip;
             op += len;
         }
         // a clean block ends exactly at `expected`; bytes after the last needed tag: decompress.hip decides (TOO_LONG or ignored)
