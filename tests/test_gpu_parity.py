@@ -468,6 +468,31 @@ def test_streams_built_against_the_sub_chain_decoder(decode, monkeypatch):
             assert_same(f"{decode} stream {i}", h_out[out_off[i]: out_off[i] + dlen[i]].tobytes(), ref)
 
 
+def test_one_context_through_batches_of_changing_block_sizes():
+    """The decode policy of a context follows its previous batch (small-block pre-pass layout by mean block size; no pre-pass after
+    a batch of large blocks; capi.hip launch_decompress).  One context, batches of 40 / 200 / 65536 / 300 / 65536 / 40 / 1000-byte
+    blocks, each decoded twice (the second call sees the first one's read-back): every block round-trips, a sample equals the
+    oracle, whatever the context remembered."""
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    raw_all = SD.corpus_blocks([read_testdata(n) for n in CORPUS], 11, 4096, SD.MIXED_SEED, "cuda")     # 256 MiB
+    for bs in (40, 200, 65536, 300, 65536, 40, 1000):
+        nb = min(raw_all.numel() // bs, 65536)
+        assert nb >= 4096                                                 # (the small-block pre-pass is for batches of >= 4096 blocks)
+        raw = raw_all[: nb * bs]
+        in_off, in_len = cd.uniform_layout(nb, bs)
+        out, out_off, out_len, status = cd.compress(raw, in_off, in_len)
+        assert int((status != 0).sum()) == 0
+        h_out, h_off, h_len, h_raw = out.cpu().numpy(), out_off.cpu().numpy(), out_len.cpu().numpy(), raw.cpu().numpy()
+        for b in range(0, nb, max(1, nb // 64)):
+            assert_same(f"bs {bs} block {b}", h_out[h_off[b]: h_off[b] + h_len[b]].tobytes(), O.compress(h_raw[b * bs: (b + 1) * bs].tobytes()))
+        for rep in range(2):
+            back = torch.zeros_like(raw)
+            dlen, dst = cd.decompress(out, out_off, out_len, back, in_off, in_len)
+            torch.cuda.synchronize()
+            assert int((dst != 0).sum()) == 0 and bool((dlen == bs).all()), f"bs {bs} call {rep}"
+            assert torch.equal(back, raw), f"bs {bs} call {rep}"
+
+
 @pytest.mark.parametrize("bs", [64, 256, 1000, 4096])
 def test_many_small_blocks_roundtrip_and_parity(bs):               # SURVEY 8(f4); SnappyStreamTests.cs:145-192 pattern
     """Batches of small blocks take the block-per-lane decoder and the lane compressor with small tables: every block
