@@ -142,7 +142,7 @@ snp_status snp_compress_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* i
 /* nblocks independent Snappy blocks: block b reads in[in_off[b] .. +in_len[b]) (varint preamble + tags) and writes
  * at most out_cap[b] bytes at out[out_off[b] ..).  out_len[b] = declared/decoded length, status[b] per block.
  * SnappyDecompressor.cs:184-347 semantics.  One wavefront per block (decompress.hip); in batches of >= 4096 blocks, clean blocks
- * that declare at most 384 bytes are first decoded by a lane or a team of lanes each (decompress_small.hip), unless the previous
+ * that declare at most 512 bytes are first decoded by a lane or a team of lanes each (decompress_small.hip), unless the previous
  * batch of this context showed mostly larger blocks (the context keeps a 272-byte asynchronous read-back of how its last batch
  * went: a performance memory only, results do not depend on it).  While the call is in flight status[b] may transiently hold -1
  * (a block the first pass left to the second); it is final when the stream reaches the end of the call's work. */

@@ -21,7 +21,7 @@ hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
                                    hipStream_t);
 hipError_t snp_launch_decompress_small(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*,
-                                       u32, hipStream_t, u32*, u32*, u32);
+                                       u32, hipStream_t, u32*, u32*, u32, u32);
 hipError_t snp_launch_sample_caps(const u32*, u32, u32, u32*, hipStream_t);
 hipError_t snp_launch_decompress_list(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*, int,
                                       hipStream_t, const u32*, u32*, u32, u32);
@@ -69,14 +69,14 @@ struct snp_ctx {
     int compress_mode = 0;   // 0 auto by batch size, 2 fragment-per-lane with HBM tables (compress_lanes.hip), 3 fragment-per-wavefront
                              // with the table in LDS, multi-token windows (compress_win.hip)
     int win_np = 1;          // window compressor: positions per lane (SNAPPIER_HIP_WIN_NP = 1 | 2; 2 measured slower)
-    u32 small_max = 384;     // blocks declaring at most this many bytes are decoded one per LANE (decompress_small.hip); 0 = never.
-                             // Measured (profiles/r02s_small_block_crossover.jsonl): the lane kernel runs at ~190-200 GB/s whatever the block
-                             // size (uncoalesced 16-byte accesses: the same transaction-rate wall as the lane compressor), the wave kernel
-                             // (sub-chain front end) at 148 / 166 / 187 / 208 / 226 / 327 GB/s for 256 / 320 / 384 / 448 / 512 / 1024-byte blocks.
+    u32 small_max = 512;     // blocks declaring at most this many bytes go through the small-block pre-pass (decompress_small.hip: a lane or
+                             // a team of lanes per block, out of LDS); 0 = never.  Above 512 bytes the wave kernel is faster (768-1024 B:
+                             // teams 180-260 GB/s, wave kernel 280-335; profiles/r02t_team_budget.jsonl).
     u32 small_min_blocks = 4096;   // ... in batches of at least this many blocks
     bool small_lanes = false;      // SNAPPIER_HIP_SMALL=lanes: the block-per-lane kernel instead of a team of lanes per block
     bool redo_grid = false, redo_list = false;   // SNAPPIER_HIP_REDO=grid|list pins how the pre-pass's leftovers are decoded (default: by how the previous batch went)
     u32 small_team_log = 0;        // SNAPPIER_HIP_SMALL=team4|team8|team16: lanes per block (0 = the kernel's default)
+    u32 slice_fragments = 262144;   // fragments per lane-compressor launch (SNAPPIER_HIP_SLICE)
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
     DevBuf in, out, meta, work, tables, scan, small, redo;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
@@ -121,17 +121,23 @@ struct snp_ctx {
             if (!check(hipMemsetAsync(ctl, 0, 68 * 4, stream), "memset(redo list)")) return false;
             bool ok;
             if (prepass) {
-                // lanes per block, by the mean block size of the previous batch (profiles/r02t_small_block_layouts.jsonl, GB/s:
-                // 32 B: one lane 558, 4 lanes 395; 64 B: 418 / 444; 128 B: 4 lanes 435, 8 lanes 340; 256 B: 4 lanes 302, 8 lanes 351,
-                // 16 lanes 235; 384-512 B: 16 lanes 231, 8 lanes 211-216)
+                // lanes per block and LDS per wavefront, by the mean block size of the previous batch (GB/s, profiles/r02t_small_block_layouts.jsonl
+                // and r02t_team_budget.jsonl: 32 B: one lane 558, 4 lanes 395; 64 B: 418 / 444; 128 B: 4 lanes 435, 8 lanes 340; 256 B: 4 lanes
+                // 302, 8 lanes 351, 16 lanes 235; 384 B: 8 lanes 221 with 4.5 KiB of LDS per wavefront, 356 with 6.75 KiB (all eight blocks in
+                // one round), 16 lanes 238; 512 B: 8 lanes 319 with 9 KiB, 16 lanes 237; 768-1024 B: teams 180-260, the wave kernel 335)
                 const u32 lim = small_max > 512u ? 512u : small_max;
-                u32 lay;
+                u32 lay, budget = 0;
                 if (small_lanes) lay = (small_max & 0x0fffffffu) | 0x80000000u;
                 else if (small_team_log) lay = lim | (small_team_log << 28);
                 else if (hint_mean_cap <= 48) lay = lim | 0x80000000u;
-                else lay = lim | ((hint_mean_cap <= 192 ? 2u : hint_mean_cap <= 320 ? 3u : 4u) << 28);
+                else if (hint_mean_cap <= 144) lay = lim | (2u << 28);
+                else {
+                    lay = lim | (3u << 28);
+                    const u32 want = (8u * (2u * (hint_mean_cap > 512u ? 512u : hint_mean_cap) + 64u) + 255u) & ~255u;   // eight blocks in one round
+                    budget = want < 4608u ? 4608u : want > 9216u ? 9216u : want;
+                }
                 if (!check(snp_launch_decompress_small(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
-                                                       chunk_type, lay, stream, chains ? list : nullptr, ctl, sub_cap), "decompress (small blocks) launch"))
+                                                       chunk_type, lay, stream, chains ? list : nullptr, ctl, sub_cap, budget), "decompress (small blocks) launch"))
                     return false;
                 if (chains)
                     ok = check(snp_launch_decompress_list(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status, chunk_type,
@@ -191,7 +197,7 @@ struct snp_ctx {
                                                  emit_varint, win_np, stream), "compress (windows) launch");
         // 64 KiB of table per fragment in flight: very large batches (millions of small blocks) go in slices, so the
         // workspace stays <= 16 GiB; 262 144 fragments per launch still fill the chip many times over
-        constexpr u32 kSlice = 262144;
+        const u32 kSlice = slice_fragments;
         if (!ensure_tables(nblocks < kSlice ? nblocks : kSlice) || !ensure(small, 256, "hipMalloc(scalars)")) return false;
         for (u32 first = 0; first < nblocks; first += kSlice) {
             const u32 cnt = nblocks - first < kSlice ? nblocks - first : kSlice;
@@ -383,6 +389,8 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->redo_list = rg && strcmp(rg, "list") == 0;
     const char* sn = getenv("SNAPPIER_HIP_SMALL_MIN");
     if (sn) c->small_min_blocks = static_cast<u32>(strtoul(sn, nullptr, 10));
+    const char* sf = getenv("SNAPPIER_HIP_SLICE");
+    if (sf && atoi(sf) >= 4096) c->slice_fragments = static_cast<u32>(atoi(sf));
     const char* wm = getenv("SNAPPIER_HIP_WIN_MAX");
     if (wm) c->win_max = static_cast<u32>(strtoul(wm, nullptr, 10));
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_small(const u8* __restr
 // LDS is handed out by need, not by the largest block the kernel accepts: a team takes align16(compressed bytes) + align16(its
 // capacity) + 32, the teams of a wavefront share kTeamBudget bytes (sized for 32 wavefronts per CU), and teams that do not fit
 // in one round take the next one (512-byte blocks: two rounds of 5 + 3; 256-byte blocks and smaller: one).
-constexpr u32 kTeamBudget = 4608;
+constexpr u32 kTeamBudget = 4608;                                       // default; the launcher may hand a wavefront more (fewer wavefronts per CU)
 constexpr u32 kTeamOutMax = 512;                                        // declared bytes a team accepts at most
 
 template <u32 TEAM>
@@ -190,10 +190,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
                                                               const u64* __restrict__ out_off,
                                                               const u32* __restrict__ out_cap, u32* __restrict__ out_len,
                                                               i32* __restrict__ status, const u8* __restrict__ chunk_type,
-                                                              u32 small_max, u32* __restrict__ list, u32* __restrict__ ctl, u32 sub_cap)
+                                                              u32 small_max, u32* __restrict__ list, u32* __restrict__ ctl, u32 sub_cap,
+                                                              u32 budget)
 {
     constexpr u32 kTeams = SNP_WAVE / TEAM;
-    __shared__ __attribute__((aligned(16))) u8 t_buf[kTeamBudget];
+    extern __shared__ __attribute__((aligned(16))) u8 t_buf[];          // `budget` bytes (dynamic LDS)
     const u32 lane = threadIdx.x, tl = lane & (TEAM - 1), team = lane / TEAM;
     const u32 b = blockIdx.x * kTeams + team;
     const bool live = b < nblocks;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
     }
     const u32 in_room = (n + 15u) & ~15u;
     const u32 need = in_room + 16u + ((cap + 15u) & ~15u) + 16u;        // [compressed | slack | decoded | slack]
-    bool redo = live && (cap > small_max || cap > kTeamOutMax || n < 1 || need > kTeamBudget || (chunk_type && chunk_type[b] == 1));
+    bool redo = live && (cap > small_max || cap > kTeamOutMax || n < 1 || need > budget || (chunk_type && chunk_type[b] == 1));
     bool waiting = live && !redo;                                       // teams that have not had their round yet
     u32 op = 0;
     while (__ballot(waiting)) {
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
             incl += lane >= static_cast<u32>(d) ? up : 0u;
         }
         const u32 end = static_cast<u32>(__shfl(static_cast<int>(incl), static_cast<int>(team * TEAM), SNP_WAVE));   // my team's slot ends here
-        const bool now = waiting && end <= kTeamBudget;
+        const bool now = waiting && end <= budget;
         waiting = waiting && !now;
         u8* const tin = t_buf + (end - need);
         const u32 kOut = in_room + 16u;                                 // the decoded bytes start here
@@ -370,7 +371,8 @@ extern "C" hipError_t snp_launch_sample_caps(const u32* out_cap, u32 nblocks, u3
 
 extern "C" hipError_t snp_launch_decompress_small(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                                   const u64* out_off, const u32* out_cap, u32* out_len, i32* status,
-                                                  const u8* chunk_type, u32 small_max, hipStream_t stream, u32* list, u32* ctl, u32 sub_cap)
+                                                  const u8* chunk_type, u32 small_max, hipStream_t stream, u32* list, u32* ctl, u32 sub_cap,
+                                                  u32 team_budget)
 {
     if (nblocks == 0) return hipSuccess;
     // small_max bit 31: the block-per-lane kernel (kept for A/B); bits 28-30: log2 of the team size (0 = default)
@@ -381,9 +383,11 @@ extern "C" hipError_t snp_launch_decompress_small(const u8* in, const u64* in_of
                            out_cap, out_len, status, chunk_type, lim, list, ctl, sub_cap);
         return hipGetLastError();
     }
+    const char* be = getenv("SNAPPIER_HIP_TEAM_BUDGET");                // LDS bytes per wavefront (experiments; default below)
+    const u32 budget = be && atoi(be) >= 1024 && atoi(be) <= 65536 ? static_cast<u32>(atoi(be)) / 16 * 16 : (team_budget ? team_budget : kTeamBudget);
 #define SNP_LAUNCH_TEAMS(T)                                                                                             \
-    hipLaunchKernelGGL((k_decompress_teams<T>), dim3((nblocks + SNP_WAVE / T - 1) / (SNP_WAVE / T)), dim3(SNP_WAVE), 0, stream, \
-                       in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, lim, list, ctl, sub_cap)
+    hipLaunchKernelGGL((k_decompress_teams<T>), dim3((nblocks + SNP_WAVE / T - 1) / (SNP_WAVE / T)), dim3(SNP_WAVE), budget, stream, \
+                       in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, lim, list, ctl, sub_cap, budget)
     switch (tlog ? tlog : kDefaultTeamLog) {
         case 2: SNP_LAUNCH_TEAMS(4); break;
         case 3: SNP_LAUNCH_TEAMS(8); break;
