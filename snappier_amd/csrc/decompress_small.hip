@@ -1,17 +1,21 @@
-// decompress_small.hip -- SMALL Snappy blocks, one block per LANE (gfx950).  SURVEY.md 8(f4): the "many tiny chunks" pattern
-// of Snappier.Tests/SnappyStreamTests.cs:145-192 and batches of sub-page records.
+// decompress_small.hip -- SMALL Snappy blocks (<= 512 declared bytes), several per wavefront (gfx950).  SURVEY.md 8(f4): the "many
+// tiny chunks" pattern of Snappier.Tests/SnappyStreamTests.cs:145-192 and batches of sub-page records.
 //
-// decompress.hip spends a whole wavefront on a block: a 64-position window, a 64-tag execution queue.  A 256-byte block holds
-// ~8 tags -- one window, one nearly empty batch -- and 4 M of them are 4 M workgroups (126 GB/s measured).  Here every lane
-// decodes its own block (SnappyDecompressor.DecompressAllTags + Append / AppendFromSelf, SnappyDecompressor.cs:184-347,
-// 568-611; copy semantics CopyHelpers.cs:222-230), 64 blocks per wavefront, and the loop is shaped so that one tag costs
-// ONE dependent memory round trip:
+// decompress.hip spends a whole wavefront on a block: a 2 KiB super-window, 64-tag execution batches.  A 256-byte block holds
+// ~10 tags -- one nearly empty window, one nearly empty batch -- and 4 M of them are 4 M workgroups (126-148 GB/s measured).
+// The kernels here are a PRE-PASS over a batch: they finish every clean small block (SnappyDecompressor.DecompressAllTags +
+// Append / AppendFromSelf, SnappyDecompressor.cs:184-347, 568-611; copy semantics CopyHelpers.cs:222-230) and leave anything
+// else -- a larger block, an uncompressed framing chunk, and every irregularity (bad preamble, offset, length, truncated input)
+// -- untouched, marked kRedoStatus and appended to a list; decompress.hip decodes exactly those and owns every error code.
+//   k_decompress_small      one block per LANE, global memory: the best layout for blocks of <= ~48 bytes (64 blocks per wavefront)
+//   k_decompress_teams<T>   one block per TEAM of T = 4 / 8 / 16 lanes, compressed and decoded bytes in LDS, coalesced I/O
+//   k_sample_caps           what a batch that skipped the pre-pass looked like (the host's policy, capi.hip launch_decompress)
+// Which one runs, and with how much LDS per wavefront, is decided per batch from the previous batch's read-back.
+//
+// k_decompress_small: every lane decodes its own block, and the loop is shaped so that one tag costs ONE dependent memory round trip:
 //   * the next tag's bytes are requested as soon as this tag's length is known, before its copy is issued;
 //   * copies are 16-byte pieces (stores exact at the block's end, may overshoot inside it: later tags overwrite the excess);
 //   * an overlapping copy (offset < length) doubles the written prefix: log2(length / offset) steps instead of a byte loop.
-// This kernel only ever FINISHES clean blocks of at most `small_max` declared bytes.  Anything else -- a larger block, an
-// uncompressed framing chunk, and every irregularity (bad preamble, offset, length, truncated input) -- is left untouched
-// and marked kRedoStatus; decompress.hip then decodes exactly those blocks and owns every error code.
 #include "snp_device.h"
 
 namespace {
