@@ -26,7 +26,7 @@ hipError_t snp_launch_sample_caps(const u32*, u32, u32, u32*, hipStream_t);
 hipError_t snp_launch_decompress_list(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*, int,
                                       hipStream_t, const u32*, u32*, u32, u32);
 hipError_t snp_launch_compress_lanes(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, void*,
-                                     u32*, hipStream_t);
+                                     u32*, hipStream_t, int);
 size_t snp_compress_lanes_workspace(u32);
 hipError_t snp_probe_tables(void*, u32, hipStream_t, float*);
 hipError_t snp_launch_crc32c(const u8*, const u64*, const u32*, u32, int, u32*, const u32*, i32*, hipStream_t);
@@ -76,7 +76,8 @@ struct snp_ctx {
     bool small_lanes = false;      // SNAPPIER_HIP_SMALL=lanes: the block-per-lane kernel instead of a team of lanes per block
     bool redo_grid = false, redo_list = false;   // SNAPPIER_HIP_REDO=grid|list pins how the pre-pass's leftovers are decoded (default: by how the previous batch went)
     u32 small_team_log = 0;        // SNAPPIER_HIP_SMALL=team4|team8|team16: lanes per block (0 = the kernel's default)
-    u32 slice_fragments = 262144;   // fragments per lane-compressor launch (SNAPPIER_HIP_SLICE)
+    u32 slice_fragments = 262144;   // fragments per lane-compressor launch (SNAPPIER_HIP_SLICE pins it)
+    bool slice_pinned = false;
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
     DevBuf in, out, meta, work, tables, scan, small, redo;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
@@ -197,16 +198,43 @@ struct snp_ctx {
                                                  emit_varint, win_np, stream), "compress (windows) launch");
         // 64 KiB of table per fragment in flight: very large batches (millions of small blocks) go in slices, so the
         // workspace stays <= 16 GiB; 262 144 fragments per launch still fill the chip many times over
-        const u32 kSlice = slice_fragments;
+        if (chint && chint_ev && chint_pending && hipEventQuery(chint_ev) == hipSuccess) {
+            chint_pending = false;
+            chint_small = chint[0] != 0 && chint[0] <= 512;
+        } else {
+            (void)hipGetLastError();
+        }
+        const u32 kSlice = (chint_small && !slice_pinned) ? 65536u : slice_fragments;
         if (!ensure_tables(nblocks < kSlice ? nblocks : kSlice) || !ensure(small, 256, "hipMalloc(scalars)")) return false;
+        // Launch shape by fragment size: 64 KiB fragments want 64 fragments per wavefront and 262 144 per launch, fragments of at most
+        // 512 bytes 32 per wavefront and 65 536 per launch (256-byte blocks 36 -> 43.5 GB/s, 64-byte 31 -> 35; 1 KiB and up prefer the
+        // former: profiles/r02w_small_block_compress.jsonl).  What the fragments are like is known only on the device, so the longest
+        // fragment of the previous launch comes back with an asynchronous 4-byte copy (read above, only once it has landed) and this
+        // batch is assumed to be alike; results do not depend on it.
+        const int lanes_per_wave = chint_small ? 32 : 0;
         for (u32 first = 0; first < nblocks; first += kSlice) {
             const u32 cnt = nblocks - first < kSlice ? nblocks - first : kSlice;
             if (!check(snp_launch_compress_lanes(d_in, in_off + first, in_len + first, cnt, d_out, out_off + first,
                                                  out_len + first, status + first, variant, emit_varint, tables.p,
-                                                 static_cast<u32*>(small.p), stream),
+                                                 static_cast<u32*>(small.p), stream, lanes_per_wave),
                        "compress (lanes) launch"))
                 return false;
         }
+        if (chint_ready() && !chint_pending) {                          // this batch's longest fragment, for the next one
+            if (hipMemcpyAsync(chint, small.p, 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipEventRecord(chint_ev, stream) == hipSuccess)
+                chint_pending = true;
+            else
+                (void)hipGetLastError();
+        }
+        return true;
+    }
+    u32* chint = nullptr;                                // pinned: the longest fragment of the previous lane-compressor launch
+    hipEvent_t chint_ev = nullptr;
+    bool chint_pending = false, chint_small = false;
+    bool chint_ready()
+    {
+        if (!chint && hipHostMalloc(reinterpret_cast<void**>(&chint), 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); chint = nullptr; return false; }
+        if (!chint_ev && hipEventCreateWithFlags(&chint_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); chint_ev = nullptr; return false; }
         return true;
     }
 
@@ -390,7 +418,7 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     const char* sn = getenv("SNAPPIER_HIP_SMALL_MIN");
     if (sn) c->small_min_blocks = static_cast<u32>(strtoul(sn, nullptr, 10));
     const char* sf = getenv("SNAPPIER_HIP_SLICE");
-    if (sf && atoi(sf) >= 4096) c->slice_fragments = static_cast<u32>(atoi(sf));
+    if (sf && atoi(sf) >= 4096) { c->slice_fragments = static_cast<u32>(atoi(sf)); c->slice_pinned = true; }
     const char* wm = getenv("SNAPPIER_HIP_WIN_MAX");
     if (wm) c->win_max = static_cast<u32>(strtoul(wm, nullptr, 10));
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
@@ -415,6 +443,8 @@ void snp_ctx_destroy(snp_ctx* c)
             if (b->p) (void)hipFree(b->p);
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);
         if (c->hint_ev) (void)hipEventDestroy(c->hint_ev);
+        if (c->chint_ev) (void)hipEventDestroy(c->chint_ev);
+        if (c->chint) (void)hipHostFree(c->chint);
         if (c->hint) (void)hipHostFree(c->hint);
         if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
         for (auto& e : c->copy_ev) if (e) (void)hipEventDestroy(e);

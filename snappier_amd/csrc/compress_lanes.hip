@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void k_max_len(const u32* __restrict__ in_len,
 
 extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                                 const u64* out_off, u32* out_len, i32* status, int variant,
-                                                int emit_varint, void* tables, u32* max_len, hipStream_t stream)
+                                                int emit_varint, void* tables, u32* max_len, hipStream_t stream, int lanes_per_wave)
 {
     if (nblocks == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(max_len, 0, sizeof(u32), stream);
@@ -604,7 +604,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // Fragments per wavefront: 64 when there are enough fragments to fill the chip that way; fewer (partially filled
     // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
     const char* env = getenv("SNAPPIER_HIP_LANES_PER_WAVE");
-    u32 per = env ? static_cast<u32>(atoi(env)) : (nblocks >= 131072 ? 64u : nblocks >= 8192 ? 32u : 16u);   // measured: scripts/sweep_layouts.py
+    u32 per = env ? static_cast<u32>(atoi(env)) : lanes_per_wave ? static_cast<u32>(lanes_per_wave) : (nblocks >= 131072 ? 64u : nblocks >= 8192 ? 32u : 16u);   // measured: scripts/sweep_layouts.py
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
     const u32 grid = (nblocks + per - 1) / per;
     // Output-store options (bit 0: a short literal may overshoot with one 16-byte store, bit 1: tag + body of a literal in
