@@ -8,7 +8,14 @@ nb = int(os.environ.get("BLOCKS", "4096"))
 kind = os.environ.get("DATA", "html")
 html = open("tests/golden/testdata/html", "rb").read()
 cd = SB.BlockCodec(0, S.HASH_CRC32C)
-raw = SD.html_like_blocks(html, 0, nb, "cuda") if kind == "html" else SD.low_entropy_blocks(0, nb, "cuda")
+if kind == "html":
+    raw = SD.html_like_blocks(html, 0, nb, "cuda")
+elif kind == "low":
+    raw = SD.low_entropy_blocks(0, nb, "cuda")
+else:
+    td = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "testdata")
+    names = ["alice29.txt", "asyoulik.txt", "fireworks.jpeg", "geo.protodata", "html", "html_x_4", "kppkn.gtb", "lcet10.txt", "paper-100k.pdf", "plrabn12.txt", "urls.10K"]
+    raw = SD.corpus_blocks([open(os.path.join(td, n), "rb").read() for n in names if os.path.exists(os.path.join(td, n))], 0, nb, SD.MIXED_SEED, "cuda")
 in_off, in_len = cd.uniform_layout(nb)
 out, out_off, out_len, st = cd.compress(raw, in_off, in_len)
 back = torch.empty_like(raw)
