@@ -46,6 +46,16 @@ public sealed class GpuContext : SafeHandle
     /// <summary>which: 0 large blocks decoded one wavefront per 64 KiB fragment, 1 fell back to one wavefront, 2/3 workspace probe.</summary>
     public ulong Counter(int which) => NativeMethods.snp_ctx_counter(handle, which);
 
+    /// <summary>snp_ctx_set_option: e.g. (SnpOption.TableProbeMaxBytes, 32L &lt;&lt; 30) in a process that shares the GPU, or
+    /// (SnpOption.DecodeLayout, 1) before a batch of 64 KiB blocks when the previous batch was small blocks.</summary>
+    public void SetOption(SnpOption option, long value) => Snappy.ThrowIfFailed(NativeMethods.snp_ctx_set_option(handle, (int)option, value));
+
+    public long GetOption(SnpOption option)
+    {
+        Snappy.ThrowIfFailed(NativeMethods.snp_ctx_get_option(handle, (int)option, out long v));
+        return v;
+    }
+
     public void Synchronize() => Snappy.ThrowIfFailed(NativeMethods.snp_ctx_synchronize(handle));
 
     internal IntPtr Handle => handle;

@@ -22,6 +22,21 @@ public enum SnpStatus : int
     TruncatedStream = 11,
 }
 
+/// <summary>snp_option (include/snappier_hip.h): per-context configuration; no option changes a result.</summary>
+public enum SnpOption : int
+{
+    DecodeLayout = 1,           // 0 by the previous batch, 1 one block per wavefront, 2 a lane per small block, 3/4/5 a team of 4/8/16 lanes
+    SmallBlockMax = 2,
+    SmallBlockMinBatch = 3,
+    CompressLayout = 4,         // 0 by batch size, 2 fragment per lane (HBM tables), 3 fragment per wavefront (LDS table)
+    CompressWindowMaxBatch = 5,
+    TableProbeTries = 6,
+    TableProbeMaxBytes = 7,     // cap on the transient footprint of the hash-table placement probe
+    ParallelDecodeMin = 8,
+    Fenced = 9,
+    DecodeLeftovers = 10,
+}
+
 public enum SnpHash : int
 {
     Crc32C = 0,             // HashTable.cs:109-117 (x64 SSE4.2 / ARM64 CRC, .NET 8+): what the managed build emits on this host
@@ -42,6 +57,8 @@ internal static unsafe class NativeMethods
     [DllImport(Lib, CallingConvention = Cc)] internal static extern IntPtr snp_ctx_last_error(IntPtr ctx);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_ctx_synchronize(IntPtr ctx);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern ulong snp_ctx_counter(IntPtr ctx, int which);
+    [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_ctx_set_option(IntPtr ctx, int option, long value);
+    [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_ctx_get_option(IntPtr ctx, int option, out long value);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern IntPtr snp_status_string(int status);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern IntPtr snp_version();
 

@@ -87,6 +87,40 @@ snp_status snp_ctx_synchronize(snp_ctx* ctx);
  *        2 = microseconds the chosen hash-table workspace took in the placement probe (0: no probe ran),
  *        3 = workspace candidates that were probed. */
 uint64_t snp_ctx_counter(const snp_ctx* ctx, int which);
+
+/* Per-context configuration.  A library loaded into a long-running service is configured through these, per context and at any
+ * time between calls (the SNAPPIER_HIP_* environment variables, read once by snp_ctx_create, remain as debug overrides and only
+ * set the initial values).  No option changes a RESULT -- bytes, lengths and status codes are the same under every setting
+ * (tests/test_gpu_parity.py, tests/test_gpu_fuzz.py run every layout against the oracle); they choose kernels and memory behaviour.
+ * snp_ctx_set_option returns SNP_ERR_BAD_ARG for an unknown option or a value outside its range and changes nothing then. */
+typedef enum snp_option {
+    /* How snp_decompress_batch lays a batch out.  0 (default): by what the context's PREVIOUS batch looked like -- small blocks
+     * (<= SNP_OPT_SMALL_BLOCK_MAX declared bytes) by a lane or a team of lanes each, the rest one block per wavefront; a workload
+     * that alternates between block sizes should pin the layout per call instead: 1 = one block per wavefront only (no small-block
+     * pre-pass), 2 = pre-pass with one lane per block, 3 / 4 / 5 = pre-pass with a team of 4 / 8 / 16 lanes per block. */
+    SNP_OPT_DECODE_LAYOUT = 1,
+    SNP_OPT_SMALL_BLOCK_MAX = 2,        /* bytes; blocks declaring at most this many take the pre-pass (0 = never; default 512) */
+    SNP_OPT_SMALL_BLOCK_MIN_BATCH = 3,  /* ... in batches of at least this many blocks (default 4096) */
+    /* snp_compress_batch: 0 (default) by batch size -- below SNP_OPT_COMPRESS_WINDOW_MAX_BATCH fragments one fragment per wavefront
+     * with the hash table in LDS, from there on one fragment per lane with the tables in an HBM workspace; 2 / 3 pin the latter / former. */
+    SNP_OPT_COMPRESS_LAYOUT = 4,
+    SNP_OPT_COMPRESS_WINDOW_MAX_BATCH = 5,   /* default 16384 */
+    /* The lane compressor keeps 64 KiB of hash table per fragment of a launch in an HBM workspace the context owns (10.7 GB for
+     * 163 840 fragments; batches above 262 144 fragments run in slices).  How fast HBM serves its random traffic depends on where
+     * the driver placed the buffer, so when a workspace of >= 1 GiB is first needed -- on the first large
+     * snp_compress_batch of a context, and again whenever a larger batch makes it grow -- the context allocates up to
+     * SNP_OPT_TABLE_PROBE_TRIES candidates (default 12, 1 = no probe), times 5 ms of table traffic on each and keeps the fastest.
+     * MEMORY BEHAVIOUR: the candidates coexist until the probe ends, within min(half of the device's free memory,
+     * SNP_OPT_TABLE_PROBE_MAX_BYTES) (default 0 = no further cap); a process that shares the GPU with other allocators should set
+     * the byte cap (or tries = 1) before its first large compress call.  The losers are freed before the call returns. */
+    SNP_OPT_TABLE_PROBE_TRIES = 6,
+    SNP_OPT_TABLE_PROBE_MAX_BYTES = 7,
+    SNP_OPT_PARALLEL_DECODE_MIN = 8,    /* snp_try_decompress: declared bytes from which ONE block is decoded a wavefront per 64 KiB fragment (0 = never; default 262144) */
+    SNP_OPT_FENCED = 9,                 /* 1 (default): a wavefront drains its stores before it reads output bytes it wrote itself; 0 relies on in-order vector memory */
+    SNP_OPT_DECODE_LEFTOVERS = 10       /* blocks the pre-pass leaves over: 0 (default) by the previous batch, 1 one workgroup per block, 2 a list for persistent wavefronts */
+} snp_option;
+snp_status snp_ctx_set_option(snp_ctx* ctx, int option, int64_t value);
+snp_status snp_ctx_get_option(const snp_ctx* ctx, int option, int64_t* out_value);
 const char* snp_status_string(int status);
 const char* snp_version(void);
 
@@ -177,8 +211,9 @@ snp_status snp_frame_decode_chunks_device(snp_ctx* ctx, const uint8_t* d_in, con
                                           int32_t* status);
 
 /* Fully device-resident decode of a framed stream that arrives WITHOUT a chunk table (SnappyStreamDecompressor.cs:53-199):
- * a device kernel walks the chunk headers (a serial chain -- each header gives the next, ~1 us per chunk), builds the
- * chunk table in d_work, then all chunks are decoded and CRC-checked in one launch each.  max_chunks bounds the table
+ * device kernels walk the chunk headers -- the stream is cut into 1 MiB spans that are walked concurrently, each from a few
+ * candidate entry points, and one wavefront then resolves which candidate of every span the true chain enters (frame_scan.hip;
+ * ~2 ms per 10 GiB) -- and build the chunk table in d_work; then all chunks are decoded and CRC-checked in one launch each.  max_chunks bounds the table
  * (a stream with more data chunks, or one that decodes to more than cap bytes, ends with SNP_ERR_OUTPUT_TOO_SMALL);
  * d_work must hold snp_frame_decode_workspace(max_chunks) bytes.  d_result (device, 2 x u64): [0] = bytes written
  * (0 unless OK), [1] = status of the stream: the first failing chunk in stream order, else the error that ended the

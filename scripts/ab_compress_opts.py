@@ -41,7 +41,9 @@ for rep in range(5):
             os.environ["SNAPPIER_HIP_CL_OPTS"] = m
         ms, (_, _, out_len, st) = run()
         res[m].append(round(ms, 2))
-        sig = int(out_len.to(torch.int64).sum().item())
+        # every mask must produce the same BYTES: total length + a CRC-32C of each block's valid bytes (computed on the device)
+        crcs = cd.crc32c(comp, comp_off, out_len)
+        sig = (int(out_len.to(torch.int64).sum().item()), int(crcs.to(torch.int64).sum().item()), int((crcs.to(torch.int64) * (torch.arange(nb, device="cuda") % 251 + 1)).sum().item()))
         ref = sig if ref is None else ref
-        assert sig == ref and int((st != 0).sum()) == 0
+        assert sig == ref and int((st != 0).sum()) == 0, (m, sig, ref)
 print(json.dumps({m: {"ms": v, "mean": round(sum(v) / len(v), 2)} for m, v in res.items()}))

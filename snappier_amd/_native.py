@@ -22,6 +22,9 @@ HEADER_PATH = os.path.join(HERE, "..", "include", "snappier_hip.h")
 HASH_CRC32C, HASH_MUL = 0, 1
 BLOCK_SIZE = 65536
 MAX_BLOCK_COMPRESSED = 76491
+# snp_option (include/snappier_hip.h)
+(OPT_DECODE_LAYOUT, OPT_SMALL_BLOCK_MAX, OPT_SMALL_BLOCK_MIN_BATCH, OPT_COMPRESS_LAYOUT, OPT_COMPRESS_WINDOW_MAX_BATCH,
+ OPT_TABLE_PROBE_TRIES, OPT_TABLE_PROBE_MAX_BYTES, OPT_PARALLEL_DECODE_MIN, OPT_FENCED, OPT_DECODE_LEFTOVERS) = range(1, 11)
 
 
 def declared_symbols() -> list[str]:
@@ -57,6 +60,8 @@ def lib() -> C.CDLL:
         "snp_ctx_last_error": (C.c_char_p, [vp]),
         "snp_ctx_synchronize": (i32, [vp]),
         "snp_ctx_counter": (u64, [vp, i32]),
+        "snp_ctx_set_option": (i32, [vp, i32, i64]),
+        "snp_ctx_get_option": (i32, [vp, i32, C.POINTER(i64)]),
         "snp_status_string": (C.c_char_p, [i32]),
         "snp_version": (C.c_char_p, []),
         "snp_max_compressed_length": (i64, [i64]),

@@ -40,6 +40,19 @@ class Context:
         """snp_ctx_counter: 0 = large blocks decoded per fragment, 1 = large blocks that fell back to one wavefront."""
         return int(N.lib().snp_ctx_counter(self._h, which))
 
+    def set_option(self, option: int, value: int):
+        """snp_ctx_set_option (N.OPT_*): kernels and memory behaviour only, never results."""
+        st = N.lib().snp_ctx_set_option(self._h, option, value)
+        if st != N.OK:
+            raise ValueError(f"snp_ctx_set_option({option}, {value}): {N.status_string(st)}")
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int64(0)
+        st = N.lib().snp_ctx_get_option(self._h, option, C.byref(v))
+        if st != N.OK:
+            raise ValueError(f"snp_ctx_get_option({option}): {N.status_string(st)}")
+        return int(v.value)
+
     def synchronize(self):
         st = N.lib().snp_ctx_synchronize(self._h)
         if st != N.OK:

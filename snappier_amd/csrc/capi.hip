@@ -67,6 +67,7 @@ struct snp_ctx {
     int table_tries = 12;    // candidates tried when a >= 1 GiB hash-table workspace is allocated (SNAPPIER_HIP_TABLE_TRIES; as many of them as fit in half
                              // of the free memory: ~10 for the 13.4 GB of the headline batch).  About one allocation in four lands on the fast level
                              // (probe 5.6 vs 6.25 ms, kernel 122-128 vs 135-139 ms): six tries missed it one time in seven, profiles/r02x_table_placement.txt
+    uint64_t table_probe_max_bytes = 0;   // SNP_OPT_TABLE_PROBE_MAX_BYTES: cap on what the placement probe's candidates may occupy together (0 = half of free memory only)
     u32 par_min = 4 * SNP_BLOCK_SIZE;   // single blocks at least this long are decoded one wavefront per 64 KiB fragment (0 = never)
     int compress_mode = 0;   // 0 auto by batch size, 2 fragment-per-lane with HBM tables (compress_lanes.hip), 3 fragment-per-wavefront
                              // with the table in LDS, multi-token windows (compress_win.hip)
@@ -75,6 +76,7 @@ struct snp_ctx {
                              // a team of lanes per block, out of LDS); 0 = never.  Above 512 bytes the wave kernel is faster (768-1024 B:
                              // teams 180-260 GB/s, wave kernel 280-335; profiles/r02t_team_budget.jsonl).
     u32 small_min_blocks = 4096;   // ... in batches of at least this many blocks
+    bool no_prepass = false;       // SNP_OPT_DECODE_LAYOUT = 1: every block by the one-block-per-wavefront kernel
     bool small_lanes = false;      // SNAPPIER_HIP_SMALL=lanes: the block-per-lane kernel instead of a team of lanes per block
     bool redo_grid = false, redo_list = false;   // SNAPPIER_HIP_REDO=grid|list pins how the pre-pass's leftovers are decoded (default: by how the previous batch went)
     u32 small_team_log = 0;        // SNAPPIER_HIP_SMALL=team4|team8|team16: lanes per block (0 = the kernel's default)
@@ -93,7 +95,7 @@ struct snp_ctx {
         // Large batches first go through the block-per-lane kernel, which finishes every clean block of <= small_max bytes
         // and marks the rest; the wave kernel then takes exactly those (all of them when every block is a 64 KiB block: the
         // first launch is then 163 840 lanes that read two words each).
-        if (small_max && nblocks >= small_min_blocks && decode_layout == 0) {
+        if (small_max && nblocks >= small_min_blocks && decode_layout == 0 && !no_prepass) {
             // Small clean blocks are finished by a pre-pass (decompress_small.hip: a lane or a team of lanes per block), which
             // appends the blocks it leaves over to a list; a chip-full of persistent wavefronts then decodes the list
             // (decompress.hip, k_decompress_chains_list: no launch per finished block -- 4 M blocks of 256 bytes 4.7 -> 3.3 ms, 64-byte
@@ -120,7 +122,8 @@ struct snp_ctx {
                 (void)hipGetLastError();
             }
             const bool chains = (fenced & 8) != 0;
-            const bool prepass = redo_list || !chains || (!redo_grid && !hint_mostly_large);
+            const bool pinned = small_lanes || small_team_log != 0;          // the caller chose the pre-pass layout: the previous batch is not asked
+            const bool prepass = redo_list || !chains || pinned || (!redo_grid && !hint_mostly_large);
             if (!check(hipMemsetAsync(ctl, 0, 68 * 4, stream), "memset(redo list)")) return false;
             bool ok;
             if (prepass) {
@@ -191,7 +194,7 @@ struct snp_ctx {
     bool launch_compress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
                          u32* out_len, i32* status, int emit_varint)
     {
-        // Measured on MI355X (profiles/r02_compress_layouts.jsonl): the window kernel (LDS tables, 1024 fragments in flight)
+        // Measured on MI355X (profiles/r02p_compress_by_batch.jsonl, r02_window_kernel.jsonl): the window kernel (LDS tables, 1024 fragments in flight)
         // runs at the same rate at any batch size and beats the single-token wave kernel everywhere; the lane kernel (HBM
         // tables) needs >= 16 384 fragments in flight before its memory-level parallelism overtakes it.
         const bool win = compress_mode == 3 || (compress_mode == 0 && nblocks < win_max);
@@ -277,11 +280,14 @@ struct snp_ctx {
         if (bytes <= tables.cap) return true;
         if (tables.p) (void)hipFree(tables.p);
         tables = DevBuf{};
-        const size_t want = bytes + bytes / 4 + 4096;
+        // (a GiB-sized workspace gets no growth slack: 25 % of 10.7 GB is 2.7 GB per candidate that nothing ever uses)
+        const size_t want = bytes >= (1ull << 30) ? bytes + 4096 : bytes + bytes / 4 + 4096;
         int tries = (bytes >= (1ull << 30) && table_tries > 1) ? table_tries : 1;
         size_t free_b = 0, total_b = 0;
         if (tries > 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {   // the candidates coexist: stay within half of what is free
-            const size_t fit = free_b / 2 / want;
+            size_t room = free_b / 2;                                        // ... and within the caller's byte cap (SNP_OPT_TABLE_PROBE_MAX_BYTES)
+            if (table_probe_max_bytes && table_probe_max_bytes < room) room = static_cast<size_t>(table_probe_max_bytes);
+            const size_t fit = room / want;
             if (fit < static_cast<size_t>(tries)) tries = fit < 1 ? 1 : static_cast<int>(fit);
         }
         void* cand[16] = {nullptr};
@@ -324,7 +330,9 @@ struct snp_ctx {
             return h2d(in.p, host_in, n, "H2D input") &&
                    launch_compress(static_cast<const u8*>(in.p), d_in_off, d_in_len, nf, d_out, d_out_off, d_out_len, d_status, emit_varint);
         const u32 per = nf >= 16384 ? 4096u : (nf + 3) / 4;
-        bool ok = true;
+        // the copy stream overwrites this->in: everything already queued on `stream` that reads it goes first (correctness must not
+        // rest on the previous call having synchronised)
+        bool ok = check(hipEventRecord(copy_ev[0], stream), "event") && check(hipStreamWaitEvent(copy_stream, copy_ev[0], 0), "wait");
         u32 k = 0;
         for (u32 first = 0; first < nf && ok; first += per, ++k) {
             const u32 cnt = nf - first < per ? nf - first : per;
@@ -336,6 +344,8 @@ struct snp_ctx {
                  launch_compress(static_cast<const u8*>(in.p), d_in_off + first, d_in_len + first, cnt, d_out, d_out_off + first,
                                  d_out_len + first, d_status + first, emit_varint);
         }
+        // a failed step returns to the caller, who may free or reuse host_in at once: no copy from it may still be in flight
+        if (!ok) (void)hipStreamSynchronize(copy_stream);
         return ok;
     }
     // copy stream: host -> device slices that overlap the kernels of the previous slice
@@ -434,6 +444,76 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
 }
 
 uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 4) ? c->counters[which] : 0; }
+
+snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
+{
+    if (!c) return SNP_ERR_BAD_ARG;
+    switch (option) {
+        case SNP_OPT_DECODE_LAYOUT:
+            if (v < 0 || v > 5) return SNP_ERR_BAD_ARG;
+            c->no_prepass = v == 1;
+            c->small_lanes = v == 2;
+            c->small_team_log = v >= 3 ? static_cast<u32>(v - 1) : 0u;   // 3 / 4 / 5 -> teams of 4 / 8 / 16 lanes
+            return SNP_OK;
+        case SNP_OPT_SMALL_BLOCK_MAX:
+            if (v < 0 || v > 0x0fffffff) return SNP_ERR_BAD_ARG;
+            c->small_max = static_cast<u32>(v);
+            return SNP_OK;
+        case SNP_OPT_SMALL_BLOCK_MIN_BATCH:
+            if (v < 1 || v > 0xffffffffll) return SNP_ERR_BAD_ARG;
+            c->small_min_blocks = static_cast<u32>(v);
+            return SNP_OK;
+        case SNP_OPT_COMPRESS_LAYOUT:
+            if (v != 0 && v != 2 && v != 3) return SNP_ERR_BAD_ARG;
+            c->compress_mode = static_cast<int>(v);
+            return SNP_OK;
+        case SNP_OPT_COMPRESS_WINDOW_MAX_BATCH:
+            if (v < 0 || v > 0xffffffffll) return SNP_ERR_BAD_ARG;
+            c->win_max = static_cast<u32>(v);
+            return SNP_OK;
+        case SNP_OPT_TABLE_PROBE_TRIES:
+            if (v < 1 || v > 16) return SNP_ERR_BAD_ARG;
+            c->table_tries = static_cast<int>(v);
+            return SNP_OK;
+        case SNP_OPT_TABLE_PROBE_MAX_BYTES:
+            if (v < 0) return SNP_ERR_BAD_ARG;
+            c->table_probe_max_bytes = static_cast<uint64_t>(v);
+            return SNP_OK;
+        case SNP_OPT_PARALLEL_DECODE_MIN:
+            if (v < 0 || v > 0x7fffffff) return SNP_ERR_BAD_ARG;
+            c->par_min = static_cast<u32>(v);
+            return SNP_OK;
+        case SNP_OPT_FENCED:
+            if (v != 0 && v != 1) return SNP_ERR_BAD_ARG;
+            c->fenced = (c->fenced & ~1) | static_cast<int>(v);
+            return SNP_OK;
+        case SNP_OPT_DECODE_LEFTOVERS:
+            if (v < 0 || v > 2) return SNP_ERR_BAD_ARG;
+            c->redo_grid = v == 1;
+            c->redo_list = v == 2;
+            return SNP_OK;
+        default:
+            return SNP_ERR_BAD_ARG;
+    }
+}
+
+snp_status snp_ctx_get_option(const snp_ctx* c, int option, int64_t* out)
+{
+    if (!c || !out) return SNP_ERR_BAD_ARG;
+    switch (option) {
+        case SNP_OPT_DECODE_LAYOUT: *out = c->no_prepass ? 1 : c->small_lanes ? 2 : c->small_team_log ? c->small_team_log + 1 : 0; return SNP_OK;
+        case SNP_OPT_SMALL_BLOCK_MAX: *out = c->small_max; return SNP_OK;
+        case SNP_OPT_SMALL_BLOCK_MIN_BATCH: *out = c->small_min_blocks; return SNP_OK;
+        case SNP_OPT_COMPRESS_LAYOUT: *out = c->compress_mode; return SNP_OK;
+        case SNP_OPT_COMPRESS_WINDOW_MAX_BATCH: *out = c->win_max; return SNP_OK;
+        case SNP_OPT_TABLE_PROBE_TRIES: *out = c->table_tries; return SNP_OK;
+        case SNP_OPT_TABLE_PROBE_MAX_BYTES: *out = static_cast<int64_t>(c->table_probe_max_bytes); return SNP_OK;
+        case SNP_OPT_PARALLEL_DECODE_MIN: *out = c->par_min; return SNP_OK;
+        case SNP_OPT_FENCED: *out = c->fenced & 1; return SNP_OK;
+        case SNP_OPT_DECODE_LEFTOVERS: *out = c->redo_grid ? 1 : c->redo_list ? 2 : 0; return SNP_OK;
+        default: return SNP_ERR_BAD_ARG;
+    }
+}
 
 void snp_ctx_destroy(snp_ctx* c)
 {

@@ -133,16 +133,17 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_small(const u8* __restr
         else { len = hi6 + 1; off = trailer; }
         const u32 nip = type == 0 ? body + len : body;
         // irregular -> leave it all to decompress.hip (TOO_LONG / BAD_OFFSET / partial literal)
-        if (len > expected - op || (type == 0 ? (len > n - body) : (off == 0 || off > op))) { redo = true; break; }
+        // (len - 1 >= ...: a long literal whose 4-byte length is 0xFFFFFFFF makes len wrap to 0 -- the reference sees 2^32 bytes and fails)
+        if (len - 1u >= expected - op || (type == 0 ? (len > n - body) : (off == 0 || off > op))) { redo = true; break; }
         // request the next tag now: it does not depend on this tag's copy
         have = nip + 8 <= n;
         u64 qn = 0;
         if (have) qn = ld64u(src + nip);
         u8* d = dst + op;
         if (type == 0) {                                                // literal  :262-302, Append :568-589
-            copy_pieces(d, src + body, len, body + len + 16 <= n, op + len + 16 <= cap);
+            copy_pieces(d, src + body, len, body + len + 16 <= n, op + len + 16 <= expected);
         } else if (off >= len || off >= 16) {                           // pieces never read what they write
-            copy_pieces(d, d - off, len, true, op + len + 16 <= cap);   // the source's slop is earlier output of this block
+            copy_pieces(d, d - off, len, true, op + len + 16 <= expected);   // the source's slop is earlier output of this block; stores stay below `expected`
         } else {
             // offset < length and < 16: the written prefix doubles (IncrementalCopy semantics: out[op+k] = out[op-off+k])
             u32 have_b = off;                                           // bytes of the pattern run available behind op + done
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
     }
     const u32 in_room = (n + 15u) & ~15u;
     const u32 need = in_room + 16u + ((cap + 15u) & ~15u) + 16u;        // [compressed | slack | decoded | slack]
-    bool redo = live && (cap > small_max || cap > kTeamOutMax || n < 1 || need > budget || (chunk_type && chunk_type[b] == 1));
+    // (n bounded first: (n + 15) & ~15 wraps for n >= 0xFFFFFFF1 and the block would be admitted with a tiny `need`)
+    bool redo = live && (cap > small_max || cap > kTeamOutMax || n < 1 || n > 2 * kTeamOutMax + 64 || need > budget || (chunk_type && chunk_type[b] == 1));
     bool waiting = live && !redo;                                       // teams that have not had their round yet
     u32 op = 0;
     while (__ballot(waiting)) {

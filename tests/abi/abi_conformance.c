@@ -41,6 +41,8 @@ typedef int32_t (*fn_ctx_set_stream)(void*, void*);
 typedef const char* (*fn_ctx_last_error)(const void*);
 typedef int32_t (*fn_ctx_synchronize)(void*);
 typedef uint64_t (*fn_ctx_counter)(const void*, int32_t);
+typedef int32_t (*fn_ctx_set_option)(void*, int32_t, int64_t);
+typedef int32_t (*fn_ctx_get_option)(const void*, int32_t, int64_t*);
 typedef const char* (*fn_status_string)(int32_t);
 typedef const char* (*fn_version)(void);
 typedef int64_t (*fn_len)(int64_t);
@@ -66,7 +68,7 @@ int main(int argc, char** argv)
     /* every DllImport of NativeMethods.cs must resolve */
     static const char* all[] = {
         "snp_ctx_create", "snp_ctx_destroy", "snp_ctx_set_stream", "snp_ctx_last_error", "snp_ctx_synchronize", "snp_ctx_counter",
-        "snp_status_string", "snp_version", "snp_max_compressed_length", "snp_max_fragment_compressed_length",
+        "snp_ctx_set_option", "snp_ctx_get_option", "snp_status_string", "snp_version", "snp_max_compressed_length", "snp_max_fragment_compressed_length",
         "snp_get_uncompressed_length", "snp_try_compress", "snp_try_decompress", "snp_crc32c", "snp_frame_max_encoded_length",
         "snp_frame_encode", "snp_frame_decoded_length", "snp_frame_decode", "snp_compress_batch", "snp_decompress_batch",
         "snp_crc32c_batch", "snp_concat_batch", "snp_frame_encode_workspace", "snp_frame_encode_device",
@@ -78,6 +80,8 @@ int main(int argc, char** argv)
     fn_ctx_destroy ctx_destroy = (fn_ctx_destroy)must(lib, "snp_ctx_destroy");
     fn_ctx_last_error last_error = (fn_ctx_last_error)must(lib, "snp_ctx_last_error");
     fn_ctx_counter counter = (fn_ctx_counter)must(lib, "snp_ctx_counter");
+    fn_ctx_set_option set_option = (fn_ctx_set_option)must(lib, "snp_ctx_set_option");
+    fn_ctx_get_option get_option = (fn_ctx_get_option)must(lib, "snp_ctx_get_option");
     fn_status_string status_string = (fn_status_string)must(lib, "snp_status_string");
     fn_version version = (fn_version)must(lib, "snp_version");
     fn_len max_len = (fn_len)must(lib, "snp_max_compressed_length");
@@ -115,6 +119,10 @@ int main(int argc, char** argv)
         const uint8_t hdr_only[] = {0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59};
         EXPECT(frame_decoded_length(hdr_only, sizeof hdr_only, &total) == SNP_OK && total == 0);
     }
+    {
+        int64_t v = 0;                                                   /* GpuContext.SetOption / GetOption on a dead handle */
+        EXPECT(set_option(NULL, SNP_OPT_DECODE_LAYOUT, 1) == SNP_ERR_BAD_ARG && get_option(NULL, SNP_OPT_DECODE_LAYOUT, &v) == SNP_ERR_BAD_ARG);
+    }
     void* ctx = NULL;
     EXPECT(ctx_create(0, 7, NULL, &ctx) == SNP_ERR_BAD_ARG && ctx == NULL);      /* unknown hash variant */
     const int32_t st_create = ctx_create(0, SNP_HASH_CRC32C, NULL, &ctx);
@@ -128,6 +136,18 @@ int main(int argc, char** argv)
     EXPECT(st_create == SNP_OK && ctx != NULL);
     if (!ctx) return 1;
     EXPECT(last_error(ctx) != NULL);
+    {
+        /* GpuContext.SetOption: every option round-trips, out-of-range values and unknown options change nothing */
+        int64_t v = -1;
+        EXPECT(get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 0);
+        EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 4) == SNP_OK && get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 4);
+        EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 6) == SNP_ERR_BAD_ARG && get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 4);
+        EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 0) == SNP_OK);
+        EXPECT(set_option(ctx, SNP_OPT_TABLE_PROBE_MAX_BYTES, (int64_t)32 << 30) == SNP_OK && get_option(ctx, SNP_OPT_TABLE_PROBE_MAX_BYTES, &v) == SNP_OK && v == ((int64_t)32 << 30));
+        EXPECT(set_option(ctx, SNP_OPT_TABLE_PROBE_TRIES, 0) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_TABLE_PROBE_TRIES, 3) == SNP_OK);
+        EXPECT(get_option(ctx, SNP_OPT_SMALL_BLOCK_MAX, &v) == SNP_OK && v == 512);
+        EXPECT(set_option(ctx, 999, 1) == SNP_ERR_BAD_ARG && get_option(ctx, 999, &v) == SNP_ERR_BAD_ARG && get_option(ctx, SNP_OPT_FENCED, NULL) == SNP_ERR_BAD_ARG);
+    }
 
     /* ---- device: the sequences of Snappy.cs ------------------------------------------------------------------ */
     FILE* f = argc > 3 ? fopen(argv[3], "rb") : NULL;

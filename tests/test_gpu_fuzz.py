@@ -238,3 +238,104 @@ def test_fuzz_small_blocks_corrupted_streams_equal_oracle(layout, monkeypatch):
         assert ok.size > nb // 10 and ok.size < nb
     log_session(test="small_blocks_corrupted_streams_equal_oracle", layout=layout, rounds=ROUNDS, blocks_per_round=nb,
                 blocks_compared=ROUNDS * nb, seeds=[4242 + r for r in range(ROUNDS)], result="all statuses, lengths and bytes equal")
+
+
+TAXONOMY = [
+    bytes([5, 0x00]), bytes([4, 0x0C, 97, 98, 99, 100]), bytes([4, 0x10, 97, 98, 99, 100, 101]),
+    bytes([8, 0x0C, 97, 98, 99, 100, 0x01, 0x00]), bytes([8, 0x0C, 97, 98, 99, 100, 0x01, 0x05]),
+    bytes([8, 0x0C, 97, 98, 99, 100, 0x01, 0x04]), bytes([8, 0x00, 97, 0x1A, 0x01, 0x00]),
+    bytes([6, 0x00, 97, 0x13, 0x01, 0x00, 0x00, 0x00]), bytes([8, 0x0C, 97, 98, 99, 100, 0x02]),
+    bytes([0x80]), bytes([0xFF] * 6), bytes([0xFF, 0xFF, 0xFF, 0xFF, 0x7F, 0]), bytes([0]),
+    bytes([3, 0xFC, 0xFF, 0xFF, 0xFF, 0xFF, 1, 2, 3]),            # 4-byte literal length 2^32, the input ends inside it
+    bytes([3, 0xFC, 0xFF, 0xFF, 0xFF, 0xFF, 0x08, 97, 98, 99]),   # the same length followed by a well-formed literal: skipping the 2^32 tag would "succeed" 
+    bytes([3, 0xFC, 0xFF, 0xFF, 0xFF, 0xFF, 0x08, 97, 98, 99] + [0] * 16),
+    bytes([70, 0x00, 97]) + bytes([0xFE, 0x01, 0x00]) + bytes([0x12, 0x01, 0x00]),   # 64-byte + 5-byte pattern copies
+    bytes([3, 0x08, 97, 98, 99]), bytes([12, 0x08, 97, 98, 99, 0x15, 0x03, 0x01, 0x03]),
+]
+
+
+@pytest.mark.parametrize("layout", ["lanes", "team4", "team8", "team16"])
+def test_error_taxonomy_through_every_small_block_layout(layout, monkeypatch):
+    """The decoder's status vectors (test_decoder_error_taxonomy_matches_oracle) as a BATCH, so that the small-block pre-pass takes
+    them, through every layout: status, length and bytes equal the oracle's whichever layout the policy would have picked, and
+    nothing is written at or beyond out_len when the capacity is larger than the declared length."""
+    monkeypatch.setenv("SNAPPIER_HIP_SMALL", layout)
+    monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
+    monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "512")
+    monkeypatch.setenv("SNAPPIER_HIP_REDO", "list")
+    rng = np.random.default_rng(99)
+    text = np.frombuffer(read_testdata("html"), dtype=np.uint8)
+    streams, caps = [], []
+    for rep in range(40):                                           # 40 x (vectors + clean blocks), shuffled positions inside the wavefronts
+        for v in TAXONOMY:
+            streams.append(np.frombuffer(v, dtype=np.uint8).copy())
+            caps.append(128)
+        for _ in range(24):
+            n = int(rng.integers(1, 300))
+            s = int(rng.integers(0, len(text) - n))
+            streams.append(np.frombuffer(O.compress(text[s: s + n].tobytes()), dtype=np.uint8).copy())
+            caps.append(n + int(rng.integers(0, 40)))               # capacity >= declared length: the slack must stay untouched
+    order = rng.permutation(len(streams))
+    streams = [streams[i] for i in order]
+    caps = np.array([caps[i] for i in order], dtype=np.int32)
+    nb = len(streams)
+    sdata, s_off, s_len = batch_of(streams)
+    out_off = np.zeros(nb, dtype=np.int64)
+    out_off[1:] = np.cumsum(caps[:-1].astype(np.int64) + 64)
+    total = int(out_off[-1]) + int(caps[-1]) + 64
+    ref, ref_len, ref_st = O.decompress_batch(sdata, s_off.astype(np.uint64), s_len.astype(np.uint32), out_off.astype(np.uint64),
+                                              caps.astype(np.uint32), total, THREADS)
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    for call in range(2):                                           # the second call runs under the policy the first one taught the context
+        out = torch.full((total,), 0xA5, dtype=torch.uint8, device="cuda")
+        dlen, dst = cd.decompress(dev(sdata), dev(s_off), dev(s_len), out, dev(out_off), dev(caps))
+        torch.cuda.synchronize()
+        dlen, dst, outh = dlen.cpu().numpy(), dst.cpu().numpy(), out.cpu().numpy()
+        bad = np.nonzero(dst != ref_st)[0]
+        assert bad.size == 0, f"{layout} call {call}: status differs at {bad[:8]}: got {dst[bad[:8]]} want {ref_st[bad[:8]]}, streams {[streams[i].tobytes().hex() for i in bad[:3]]}"
+        ok = np.nonzero(ref_st == 0)[0]
+        assert (dlen[ok] == ref_len[ok]).all()
+        for b in ok:
+            o, l, c = int(out_off[b]), int(ref_len[b]), int(caps[b])
+            assert np.array_equal(outh[o: o + l], ref[o: o + l]), f"{layout}: block {b} bytes"
+            assert (outh[o + l: o + c + 64] == 0xA5).all(), f"{layout}: block {b} wrote beyond its {l} bytes (cap {c})"
+
+
+def test_context_options_pin_layouts_without_changing_results():
+    """snp_ctx_set_option (include/snappier_hip.h): decode layout, small-block thresholds, compress layout, probe cap -- set through
+    the C-ABI between calls on ONE context, alternating block sizes (the workload whose policy would otherwise come from the previous
+    batch): every setting returns the oracle's bytes; bad values are rejected and change nothing."""
+    N = S._native
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    ctx = cd.ctx
+    assert ctx.get_option(N.OPT_DECODE_LAYOUT) == 0 and ctx.get_option(N.OPT_SMALL_BLOCK_MAX) == 512
+    with pytest.raises(ValueError):
+        ctx.set_option(N.OPT_DECODE_LAYOUT, 9)
+    with pytest.raises(ValueError):
+        ctx.set_option(12345, 0)
+    assert ctx.get_option(N.OPT_DECODE_LAYOUT) == 0
+    ctx.set_option(N.OPT_TABLE_PROBE_MAX_BYTES, 1 << 30)
+    ctx.set_option(N.OPT_SMALL_BLOCK_MIN_BATCH, 1)
+    html = read_testdata("html")
+    rng = np.random.default_rng(5)
+    small = [np.frombuffer(html[s: s + n], dtype=np.uint8) for s, n in ((int(rng.integers(0, 90000)), int(rng.integers(1, 400))) for _ in range(3000))]
+    large = [np.frombuffer(html[s: s + 65536], dtype=np.uint8) for s in (0, 4099, 30000)] * 8
+    for layout, blocks in [(2, small), (1, large), (4, small), (0, large), (3, small), (5, small), (1, small), (0, small)]:
+        ctx.set_option(N.OPT_DECODE_LAYOUT, layout)
+        assert ctx.get_option(N.OPT_DECODE_LAYOUT) == layout
+        data, off, lens = batch_of(blocks)
+        for comp_layout in (0, 2, 3):
+            ctx.set_option(N.OPT_COMPRESS_LAYOUT, comp_layout)
+            out, out_off, out_len, st = cd.compress(dev(data), dev(off), dev(lens))
+            torch.cuda.synchronize()
+            assert int((st != 0).sum()) == 0
+            ol, oo, oh = out_len.cpu().numpy(), out_off.cpu().numpy(), out.cpu().numpy()
+            for b in range(0, len(blocks), max(1, len(blocks) // 40)):
+                assert oh[oo[b]: oo[b] + ol[b]].tobytes() == O.compress(blocks[b].tobytes()), (layout, comp_layout, b)
+        back = torch.zeros(int(lens.sum()) + 64, dtype=torch.uint8, device="cuda")
+        dlen, dst = cd.decompress(out, out_off, out_len, back, dev(off), dev(lens))
+        torch.cuda.synchronize()
+        assert int((dst != 0).sum()) == 0 and np.array_equal(dlen.cpu().numpy(), lens)
+        assert np.array_equal(back.cpu().numpy()[: data.size], data), layout
+    ctx.set_option(N.OPT_COMPRESS_LAYOUT, 0)
+    ctx.set_option(N.OPT_DECODE_LAYOUT, 0)

@@ -966,3 +966,4 @@ def test_full_size_config4_framing_roundtrip(codec):
     result = cd.frame_decode(framed, w, back, nb)
     torch.cuda.synchronize()
     assert result.cpu().tolist()[1] != 0
+
