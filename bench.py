@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under
                                                              torch.distributed.run, one process per GPU, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-    python bench.py --config 5 ...                          BASELINE.json configs[4]: mixed-corpus blocks, block-sharded
+    python bench.py --config 5 ...                          BASELINE.json configs[4] as the measured workload
 
 Workload (config.workload): BASELINE.json configs[1] -- 10 GiB of 64 KiB html-like blocks per GPU (163 840 blocks:
 the html fixture tiled at a per-block offset + ~1 % byte mutations, seed 0x5EED0001; weak scaling, rank r owns
@@ -15,15 +15,26 @@ blocks [r*163840, (r+1)*163840)).  One STEP = one pass of the hot path over the 
 value = uncompressed bytes that made the whole round trip, all GPUs, per second of wall time (max over ranks).
 Both directions are also reported separately from HIP-event kernel times, each with its roofline fraction:
 algorithmic bytes per launch = sum over blocks of (U_b + C_b)    /  average launch duration, against
-the 8 TB/s HBM3E peak.  cpu_baseline = the C oracle (oracle/snappy_oracle.c, a port of the same algorithm) timed on
-this host's cores over a bounded sample of the same blocks.
+the 8 TB/s HBM3E peak.
+
+When N > 1 (or with --config5-lines) the SAME run then measures BASELINE.json configs[4] -- the mixed-corpus blocks,
+block-sharded across the ranks -- and reports it as `config5_lines` (codec only / + directory gather / + compaction
+and payload gather to rank 0): one driver command covers the 8-GPU workload the north star names.  Never `value`.
+
+cpu_baseline (rank 0, N = 1): the C oracle (oracle/snappy_oracle.c, a port of the same algorithm; rebuilt on this
+host with -O3 -march=native when gcc is here) on a bounded sample of the same blocks -- 1 thread, min(cores, 64)
+threads (`value`), all cores; CRC-32C alone; libsnappy through dlopen when this host has one; the CPU model string.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
+import ctypes.util
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -35,40 +46,156 @@ sys.path.insert(0, ROOT)
 
 BLOCK = 65536
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+CORPUS = ["alice29.txt", "asyoulik.txt", "fireworks.jpeg", "geo.protodata", "html", "html_x_4", "kppkn.gtb", "lcet10.txt",
+          "paper-100k.pdf", "plrabn12.txt", "urls.10K"]       # SnappyTests.cs:8-19 corpus order
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def native_oracle():
+    """The oracle rebuilt for THIS host (-O3 -march=native), in a temporary directory; falls back to the in-tree -O2 -msse4.2 build
+    (which is what the parity tests use) when there is no compiler.  Returns (ctypes lib or None, build description)."""
+    src = os.path.join(ROOT, "oracle", "snappy_oracle.c")
+    try:
+        d = tempfile.mkdtemp(prefix="snp_oracle_")
+        so = os.path.join(d, "libsnappy_oracle_native.so")
+        subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-o", so, src], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        return so, "-O3 -march=native (built on this host)"
+    except Exception:
+        return None, "-O2 -msse4.2 (in-tree build; no compiler on this host)"
+
+
+def time_libsnappy(sample: np.ndarray, nb: int, budget_s: float):
+    """Google's C++ snappy (what Snappier is a port of), if this host has one: single-thread compress / uncompress of the same
+    blocks through its C API.  Returns a dict or a string saying it is absent."""
+    path = ctypes.util.find_library("snappy")
+    for cand in ([path] if path else []) + ["libsnappy.so.1", "/opt/conda/lib/libsnappy.so.1", "/usr/lib/x86_64-linux-gnu/libsnappy.so.1"]:
+        try:
+            L = ctypes.CDLL(cand)
+            break
+        except OSError:
+            L = None
+    if L is None:
+        return "libsnappy: not found on this host (dlopen)"
+    L.snappy_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    L.snappy_uncompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    L.snappy_max_compressed_length.restype = ctypes.c_size_t
+    L.snappy_max_compressed_length.argtypes = [ctypes.c_size_t]
+    cap = L.snappy_max_compressed_length(BLOCK)
+    comp = np.empty(nb * cap, dtype=np.uint8)
+    clen = np.zeros(nb, dtype=np.uint64)
+    back = np.empty(BLOCK, dtype=np.uint8)
+    base, cbase = sample.ctypes.data, comp.ctypes.data
+    t0 = time.perf_counter()
+    done = 0
+    for b in range(nb):
+        n = ctypes.c_size_t(cap)
+        if L.snappy_compress(base + b * BLOCK, BLOCK, cbase + b * cap, ctypes.byref(n)) != 0:
+            return "libsnappy: snappy_compress failed"
+        clen[b] = n.value
+        done = b + 1
+        if (b & 255) == 255 and time.perf_counter() - t0 > budget_s:
+            break
+    t1 = time.perf_counter()
+    for b in range(done):
+        n = ctypes.c_size_t(BLOCK)
+        if L.snappy_uncompress(cbase + b * cap, int(clen[b]), back.ctypes.data, ctypes.byref(n)) != 0 or n.value != BLOCK:
+            return "libsnappy: snappy_uncompress failed"
+    t2 = time.perf_counter()
+    u = float(done) * BLOCK
+    return {"library": str(getattr(L, "_name", "libsnappy")), "threads": 1, "blocks": done,
+            "compress_GBps": round(u / (t1 - t0) / 1e9, 3), "decompress_GBps": round(u / (t2 - t1) / 1e9, 3),
+            "note": "C++ snappy's bytes differ from Snappier's crc32c-hash bytes (other hash): a speed reference, not a parity one"}
 
 
 def cpu_baseline(raw_sample: np.ndarray, variant: int):
-    """Oracle ("port") on the host cores over a bounded sample; returns the cpu_baseline object."""
+    """Oracle ("port") on the host cores over a bounded sample; returns the cpu_baseline object (~20-30 s in total)."""
     import oracle as O
+    so, how = native_oracle()
+    if so:                                                      # same binding, the natively built object
+        O.pyoracle._SO = so
+        O.pyoracle._lib = None
     nb = raw_sample.size // BLOCK
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    ncpu = os.cpu_count() or 1
     in_off = (np.arange(nb, dtype=np.uint64) * np.uint64(BLOCK)).astype(np.uint64)
     in_len = np.full(nb, BLOCK, dtype=np.uint32)
-    O.compress_batch(raw_sample[: 64 * BLOCK], in_off[:64], in_len[:64], variant, threads)      # warm up / page in
-    reps, t_c, t_d = 0, 0.0, 0.0
-    t_start = time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
-        out, out_off, out_len, status = O.compress_batch(raw_sample, in_off, in_len, variant, threads)
-        t1 = time.perf_counter()
-        dec, dlen, dst = O.decompress_batch(out, out_off, out_len, in_off, in_len, raw_sample.size, threads)
-        t2 = time.perf_counter()
-        t_c += t1 - t0
-        t_d += t2 - t1
-        reps += 1
-        assert (status == 0).all() and (dst == 0).all()
-        if reps >= 3 or (time.perf_counter() - t_start) > 20.0:
-            break
-    assert dec.tobytes() == raw_sample.tobytes()
-    u = float(nb) * BLOCK * reps
+
+    def leg(threads: int, blocks: int, budget_s: float):
+        """round trips of the first `blocks` blocks with `threads` threads until the budget is spent; -> (compress, decompress, round trip) GB/s"""
+        blocks = min(blocks, nb)
+        s = raw_sample[: blocks * BLOCK]
+        reps, t_c, t_d = 0, 0.0, 0.0
+        t_start = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            out, out_off, out_len, status = O.compress_batch(s, in_off[:blocks], in_len[:blocks], variant, threads)
+            t1 = time.perf_counter()
+            dec, dlen, dst = O.decompress_batch(out, out_off, out_len, in_off[:blocks], in_len[:blocks], s.size, threads)
+            t2 = time.perf_counter()
+            t_c += t1 - t0
+            t_d += t2 - t1
+            reps += 1
+            assert (status == 0).all() and (dst == 0).all()
+            if reps >= 3 or (time.perf_counter() - t_start) > budget_s:
+                break
+        assert dec.tobytes() == s.tobytes()
+        u = float(blocks) * BLOCK * reps
+        return round(u / t_c / 1e9, 3), round(u / t_d / 1e9, 3), round(u / (t_c + t_d) / 1e9, 3), reps
+
+    O.compress_batch(raw_sample[: 64 * BLOCK], in_off[:64], in_len[:64], variant, min(ncpu, 64))      # warm up / page in
+    threads = max(1, min(ncpu, 64))
+    c_n, d_n, rt_n, reps = leg(threads, nb, 8.0)
+    c_1, d_1, rt_1, _ = leg(1, max(256, nb // 32), 6.0)
+    legs = {"1_thread": {"compress_GBps": c_1, "decompress_GBps": d_1, "round_trip_GBps": rt_1,
+                         "comparable_to": "Snappier.Benchmarks/BlockCompressHtml.cs:21-29, BlockDecompressHtml (single-threaded BenchmarkDotNet)"},
+            f"{threads}_threads": {"compress_GBps": c_n, "decompress_GBps": d_n, "round_trip_GBps": rt_n}}
+    if ncpu > threads:
+        c_a, d_a, rt_a, _ = leg(ncpu, nb, 6.0)
+        legs[f"all_{ncpu}_cpus"] = {"compress_GBps": c_a, "decompress_GBps": d_a, "round_trip_GBps": rt_a}
+    # CRC-32C alone (the framing format's per-chunk checksum, Crc32CAlgorithm.cs:41-158): hardware crc32 instruction, 8 bytes per step,
+    # one thread (the oracle's batch CRC is not threaded)
+    t0 = time.perf_counter()
+    crc_reps = 0
+    while crc_reps < 3 and time.perf_counter() - t0 < 3.0:
+        O.crc32c_batch(raw_sample, in_off, in_len, True)
+        crc_reps += 1
+    crc_1 = round(float(nb) * BLOCK * crc_reps / (time.perf_counter() - t0) / 1e9, 3)
     return {
-        "value": round(u / (t_c + t_d) / 1e9, 3), "unit": "GB/s uncompressed, compress+decompress round trip",
-        "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
-        "compress_GBps": round(u / t_c / 1e9, 3), "decompress_GBps": round(u / t_d / 1e9, 3),
+        "value": rt_n, "unit": "GB/s uncompressed, compress+decompress round trip",
+        "cores": threads, "host_cpus": ncpu, "cpu_model": cpu_model(), "kind": "port",
+        "compress_GBps": c_n, "decompress_GBps": d_n,
+        "legs": legs,
+        "crc32c_GBps": {"1_thread": crc_1},
+        "libsnappy": time_libsnappy(raw_sample, min(nb, 4096), 4.0),
         "sample": f"{nb} of the same html-like 64 KiB blocks x {reps} passes, {threads} threads (blocks striped), "
-                  f"C oracle built -O2 -msse4.2 (hash = SSE4.2 crc32, as Snappier on x64/.NET 8+)",
-        "note": "Snappier's C# path is not runnable on this host (no .NET runtime); the oracle is a C port of the same algorithm",
+                  f"C oracle built {how} (hash = SSE4.2 crc32, as Snappier on x64/.NET 8+)",
+        "note": "Snappier's C# path is not runnable on this host (no .NET runtime); the oracle is a C port of the same algorithm "
+                "with scalar copies -- a floor for Snappier's SIMD path, not a measurement of it",
     }
+
+
+def traffic_profile():
+    """Per-block FETCH_SIZE + WRITE_SIZE of the committed PMC passes (rocprofv3 --pmc, one counter per pass, same workload).
+    Replayed, never measured in the bench process: the object says which profile, from which commit, over how many launches."""
+    for cand in ("r03_hbm_traffic.json", "r02p_hbm_traffic.json", "r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                doc = json.load(f)
+            return doc["kernels"], {"file": f"profiles/{cand}", "kernels_commit": doc.get("source_commit", "unrecorded (profile predates round 3)"),
+                                    "launches_profiled": doc.get("launches_per_kernel", "unrecorded")}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}, None
 
 
 def main():
@@ -81,8 +208,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16384)
     ap.add_argument("--config", type=int, choices=[2, 5], default=2,
-                    help="2 = BASELINE configs[1] (html-like blocks, the headline); 5 = configs[4] (mixed-corpus blocks, "
-                         "block-sharded, plus the compaction and payload-gather lines)")
+                    help="the MEASURED workload (`value`): 2 = BASELINE configs[1] (html-like blocks, the headline); 5 = configs[4] (mixed corpus)")
+    ap.add_argument("--config5-lines", action="store_true",
+                    help="after the measured workload, also run configs[4] (mixed corpus, block-sharded) and report config5_lines; "
+                         "on by default when --gpus > 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,18 +250,19 @@ def main():
         nb = int((free - (3 << 30)) // (2 * BLOCK + 76512)) // 1024 * 1024
         print(f"[bench] only {free >> 30} GiB free: reduced to {nb} blocks per GPU", file=sys.stderr)
 
-    with open(os.path.join(ROOT, "tests", "golden", "testdata", "html"), "rb") as f:
+    td = os.path.join(ROOT, "tests", "golden", "testdata")
+    with open(os.path.join(td, "html"), "rb") as f:
         html = f.read()
     cd = SB.BlockCodec(local_rank, variant)
-    if args.config == 5:        # mixed corpus: block b takes corpus file b mod 11, rank r owns [r*nb, (r+1)*nb)
-        td = os.path.join(ROOT, "tests", "golden", "testdata")
-        names = ["alice29.txt", "asyoulik.txt", "fireworks.jpeg", "geo.protodata", "html", "html_x_4", "kppkn.gtb", "lcet10.txt",
-                 "paper-100k.pdf", "plrabn12.txt", "urls.10K"]
-        def corpus_file(f):     # html_x_4 = html repeated four times (SnappyTests.cs:8-19 corpus order)
-            return html * 4 if f == "html_x_4" else open(os.path.join(td, f), "rb").read()
-        raw = SD.corpus_blocks([corpus_file(f) for f in names], rank * nb, nb, SD.MIXED_SEED, dev)
-    else:
-        raw = SD.html_like_blocks(html, rank * nb, nb, dev)
+
+    def make_blocks(kind: int):
+        if kind == 5:       # mixed corpus: block b takes corpus file b mod 11, rank r owns [r*nb, (r+1)*nb)
+            def corpus_file(f):     # html_x_4 = html repeated four times
+                return html * 4 if f == "html_x_4" else open(os.path.join(td, f), "rb").read()
+            return SD.corpus_blocks([corpus_file(f) for f in CORPUS], rank * nb, nb, SD.MIXED_SEED, dev)
+        return SD.html_like_blocks(html, rank * nb, nb, dev)
+
+    raw = make_blocks(args.config)
     in_off, in_len = cd.uniform_layout(nb)
     comp = torch.empty(nb * cd.comp_stride, dtype=torch.uint8, device=dev)
     comp_off = torch.arange(nb, dtype=torch.int64, device=dev) * cd.comp_stride
@@ -183,60 +313,78 @@ def main():
 
     elapsed, (out_len, status, dlen, dst) = timed(lambda: step(True), args.steps)
 
-    # ---- config 5: the lines around the codec (never part of `value`) -------------------------------------------------
-    extra = {}
-    if args.config == 5:
-        def codec_only():
-            _o, _oo, ol, stt = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
-            cd.decompress(comp, comp_off, ol, back, in_off, in_len)
-            return ol, stt
-        def compact_and_gather():       # what a real 8-GPU job ends with: compact this rank's blocks, directory, payload to rank 0
-            ol, stt = out_len, status
-            stream, _dst = cd.compact(comp, comp_off, ol)
-            all_len, _all_st, _offs = sharding.gather_directory(ol, stt, nb * world)
-            got = sharding.gather_payload(stream, all_len, nb * world, dst=0)
-            return got
-        reps = max(1, min(args.steps, 3))
-        t_codec, _ = timed(codec_only, reps)
-        t_gather, gathered = timed(compact_and_gather, reps)
-        extra = {"codec_only_GBps": round(float(nb) * BLOCK * world / (t_codec / reps) / 1e9, 2),
-                 "codec_plus_directory_GBps": round(float(nb) * BLOCK * world / (elapsed / args.steps) / 1e9, 2),
-                 "compact_plus_payload_gather_ms": round(t_gather / reps * 1e3, 2),
-                 "payload_gather_GBps_compressed": (round(float(gathered.numel()) / (t_gather / reps) / 1e9, 2)
-                                                    if gathered is not None and t_gather > 0 else None)}
+    def verified(out_len, status, dlen, dst):
+        return int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and bool((dlen == BLOCK).all()) and torch.equal(back, raw)
 
     # ---- verification (outside the timed region): every status OK, decode(encode(x)) == x -----------------------
-    ok = int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0 and bool((dlen == BLOCK).all()) and torch.equal(back, raw)
-    if not ok:
+    if not verified(out_len, status, dlen, dst):
         sys.exit("[bench] round trip is NOT bit-exact -- number invalid")
     c_bytes = float(out_len.to(torch.int64).sum().item())
     u_bytes = float(nb) * BLOCK
     ms_c = float(np.mean([a.elapsed_time(b) for a, b in t_comp]))
     ms_d = float(np.mean([a.elapsed_time(b) for a, b in t_dec]))
+    cpu_sample = raw[: min(args.cpu_sample_blocks, nb) * BLOCK].cpu().numpy() if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
+
+    # ---- configs[4]: the mixed corpus, block-sharded, and the lines around the codec (never part of `value`) ----------
+    extra = {}
+    if args.config == 5 or args.config5_lines or world > 1:
+        if args.config != 5:
+            del raw
+            raw = make_blocks(5)                                # same buffers otherwise: comp, back are reused
+            step(False)
+        t5_comp, t5_dec = [], []
+        def codec_only():
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            _o, _oo, ol, stt = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
+            e1.record()
+            dl, ds = cd.decompress(comp, comp_off, ol, back, in_off, in_len)
+            e2.record()
+            t5_comp.append((e0, e1))
+            t5_dec.append((e1, e2))
+            return ol, stt, dl, ds
+        def codec_and_directory():
+            ol, stt, dl, ds = codec_only()
+            sharding.gather_directory(ol, stt, nb * world)
+            return ol, stt, dl, ds
+        reps = max(1, min(args.steps, 3))
+        t_codec, (ol5, st5, dl5, ds5) = timed(codec_only, reps)
+        t_dir, _ = timed(codec_and_directory, reps)
+        def compact_and_gather():       # what a real 8-GPU job ends with: compact this rank's blocks, directory, payload to rank 0
+            stream, _dst = cd.compact(comp, comp_off, ol5)
+            all_len, _all_st, _offs = sharding.gather_directory(ol5, st5, nb * world)
+            return sharding.gather_payload(stream, all_len, nb * world, dst=0)
+        t_gather, gathered = timed(compact_and_gather, reps)
+        if not verified(ol5, st5, dl5, ds5):
+            sys.exit("[bench] configs[4] round trip is NOT bit-exact")
+        c5 = float(ol5.to(torch.int64).sum().item())
+        extra = {"workload": f"configs[4]: {nb * world} mixed-corpus 64 KiB blocks ({nb * world * BLOCK / 2**30:.0f} GiB), block b = corpus file b mod 11, "
+                             f"rank r owns blocks [r*{nb}, (r+1)*{nb})",
+                 "n_gpus": world, "reps": reps,
+                 "codec_only_GBps": round(float(nb) * BLOCK * world / (t_codec / reps) / 1e9, 2),
+                 "codec_plus_directory_GBps": round(float(nb) * BLOCK * world / (t_dir / reps) / 1e9, 2),
+                 "compact_plus_payload_gather_ms": round(t_gather / reps * 1e3, 2),
+                 "payload_gather_GBps_compressed": (round(float(gathered.numel()) / (t_gather / reps) / 1e9, 2)
+                                                    if gathered is not None and t_gather > 0 else None),
+                 "rank0_compress_ms": round(float(np.mean([a.elapsed_time(b) for a, b in t5_comp])), 3),
+                 "rank0_decompress_ms": round(float(np.mean([a.elapsed_time(b) for a, b in t5_dec])), 3),
+                 "rank0_compression_ratio": round(c5 / u_bytes, 4),
+                 "verified": "decode(encode(x)) == x for every block of every rank's shard" if True else None}
 
     if rank == 0:
         total_u = u_bytes * world
         ms_per_step = elapsed / args.steps * 1e3
         alg = u_bytes + c_bytes                                     # U + C for compress, C + U for decompress
-        # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per
-        # pass, same workload): per-block figures x blocks of this run.  See profiles/r01k_hbm_traffic.json for the caveat
-        # on the gfx950 FETCH_SIZE calibration.
-        pmc, pmc_file = {}, None
-        for cand in ("r02p_hbm_traffic.json", "r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", cand)) as f:
-                    pmc, pmc_file = json.load(f)["kernels"], cand
-                break
-            except OSError:
-                continue
+        pmc, pmc_src = traffic_profile()
         def roof(ms, kernel):
             a = alg / (ms * 1e-3) / 1e9
             t = pmc.get(kernel)
             traffic = int((t["fetch_bytes_per_block"] + t["write_bytes_per_block"]) * nb) if t and args.hash == "crc32c" and args.config == 2 else None
             return {"bound": "hbm", "kernel": kernel, "achieved": round(a, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "traffic_source": (f"replayed: per-block FETCH_SIZE + WRITE_SIZE of profiles/{pmc_file} (separate rocprofv3 --pmc "
-                                       "passes over this workload) x blocks of this run; not measured in this process") if traffic else None,
+                    "traffic_source": (dict(pmc_src, how="replayed: per-block FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this "
+                                                         "workload x blocks of this run; not measured in this process",
+                                            launches_this_run=args.steps) if traffic and pmc_src else None),
                     "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": int(alg),
                     "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}
@@ -247,14 +395,16 @@ def main():
             r_c["table_workspace_probe"] = {"chosen_ms": S.lib().snp_ctx_counter(cd.ctx.handle, 2) / 1e3,
                                             "candidates": S.lib().snp_ctx_counter(cd.ctx.handle, 3)}
         if lanes and args.config == 2:
-            # What bounds the lane compressor is not U + C but the random 4-byte read-modify-writes of its hash tables
-            # (DESIGN.md 4.3).  Rates: scripts/microbench_random_table.hip on this GPU model (profiles/
-            # r01d_microbench_random_table.jsonl: 20.26 G read+write probes/s, 23.57 G write-only inserts/s); counts: the
-            # reference parse makes 9928 probes + 4228 post-copy inserts per fragment of this workload (first 256 blocks, counted on the CPU
-            # with the oracle).  floor = table traffic alone, nothing else in the kernel.
+            # What bounds the lane compressor is not U + C but the random accesses of its hash tables: the reference
+            # parse makes 9928 probes + 4228 post-copy inserts per fragment of this workload (counted on the CPU with the oracle), each
+            # into a uniformly random bucket of a 10.7 GB workspace.  Rates: scripts/microbench_random_table.hip on this GPU model
+            # (profiles/r01d_microbench_random_table.jsonl: 20.26 G dependent load + store probes/s, 23.57 G write-only inserts/s).
+            # floor = that table traffic alone as load + store.  Round 3 issues a probe as ONE atomic exchange, which the floor does
+            # not model: frac_of_floor > 1 means the kernel now beats the two-request form of its own traffic.
             floor_ms = nb * (9928 / 20.26e9 + 4228 / 23.57e9) * 1e3
             r_c["random_access_floor"] = {"table_probes_per_fragment": 9928, "table_inserts_per_fragment": 4228,
-                                          "floor_ms": round(floor_ms, 1), "frac_of_floor": round(floor_ms / ms_c, 3)}
+                                          "floor_ms": round(floor_ms, 1), "frac_of_floor": round(floor_ms / ms_c, 3),
+                                          "floor_models": "probe = dependent load + store (the round-1/2 kernel); round 3 probes with one atomic exchange"}
         line = {
             "metric": "uncompressed GB/s block compress+decompress, 64 KiB blocks",
             "value": round(total_u / (elapsed / args.steps) / 1e9, 3),
@@ -266,7 +416,7 @@ def main():
                                     "configs[4]: 10 GiB of mixed-corpus 64 KiB blocks per GPU (80 GiB at 8 GPUs), ") +
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
-                       "layout": "decompress: one block per wavefront (sub-chain tag parse over 2 KiB super-windows, 64 tags per execution batch staged in LDS); compress: one fragment per lane with HBM tables (>= 16384 fragments), else one per wavefront with the table in LDS",
+                       "layout": "decompress: one block per wavefront (sub-chain tag parse over 2 KiB super-windows, 64 tags per execution batch staged in LDS); compress: one fragment per lane with HBM tables, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,
@@ -277,9 +427,8 @@ def main():
         }
         if extra:
             line["config5_lines"] = extra
-        if world == 1 and not args.no_cpu_baseline:
-            ns = min(args.cpu_sample_blocks, nb)
-            line["cpu_baseline"] = cpu_baseline(raw[: ns * BLOCK].cpu().numpy(), variant)
+        if cpu_sample is not None:
+            line["cpu_baseline"] = cpu_baseline(cpu_sample, variant)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

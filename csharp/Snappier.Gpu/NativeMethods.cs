@@ -70,6 +70,8 @@ internal static unsafe class NativeMethods
     // ---- single buffer, host pointers (blocking)
     [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_try_compress(IntPtr ctx, byte* input, nuint n, byte* output, nuint cap, out nuint written);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_try_decompress(IntPtr ctx, byte* input, nuint n, byte* output, nuint cap, out nuint written);
+    [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_try_compress_segments(IntPtr ctx, byte** segments, nuint* segmentLengths, uint nseg, byte* output, nuint cap, out nuint written);
+    [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_try_decompress_segments(IntPtr ctx, byte** segments, nuint* segmentLengths, uint nseg, byte* output, nuint cap, out nuint written);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_crc32c(IntPtr ctx, byte* input, nuint n, int masked, out uint crc);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern long snp_frame_max_encoded_length(long n);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_frame_encode(IntPtr ctx, byte* input, nuint n, byte* output, nuint cap, out nuint written);

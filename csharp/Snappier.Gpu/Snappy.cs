@@ -9,6 +9,38 @@ namespace Snappier.Gpu;
 
 public static unsafe class Snappy
 {
+    // ---- routing ------------------------------------------------------------------------------------------------------------
+    // One host-pointer call into the library costs a fixed ~0.3 ms (decompress) to ~1.5 ms (compress) of launches and PCIe round
+    // trips before the first byte moves, then runs at 25-38 GB/s PCIe-inclusive (profiles/r02p_host_api.jsonl: 64 KiB 0.04 / 0.2 GB/s,
+    // 1 MiB 0.7 / 1.6, 16 MiB 7.4 / 12.6, 256 MiB 25 / 24).  Managed Snappier does ~0.5-1 GB/s compress and ~1-3 GB/s decompress on
+    // one core whatever the size, so a single call breaks even at 1-2 MiB and the GPU is worth its fixed cost from a few MiB on.
+    // Below these thresholds (and whenever no HIP device is usable) the call stays on the managed path; the BYTES are the same
+    // either way (same parse, same TableEntry hash: SnpHash.Crc32C is what managed Snappier uses on x64 / ARM64 .NET 8+).
+    // Many small inputs belong in one batch call instead (SnappyStreamChunkCodec, or snp_compress_batch from a device-resident caller).
+
+    /// <summary>Inputs shorter than this are compressed by managed Snappier (default 4 MiB; 0 = always the GPU).</summary>
+    public static int MinGpuCompressBytes { get; set; } = 4 << 20;
+
+    /// <summary>Blocks that declare fewer bytes than this are decompressed by managed Snappier (default 4 MiB; 0 = always the GPU).</summary>
+    public static int MinGpuDecompressBytes { get; set; } = 4 << 20;
+
+    private static bool UseGpuForCompress(long inputLength) => inputLength >= MinGpuCompressBytes && GpuContext.IsAvailable;
+
+    private static bool UseGpuForDecompress(ReadOnlySpan<byte> input)
+    {
+        if (MinGpuDecompressBytes > 0)
+        {
+            // the declared length decides (VarIntEncoding.Read, host-only): a malformed preamble goes to the managed path, which
+            // throws the reference's own exception for it
+            fixed (byte* pin = input)
+            {
+                if (NativeMethods.snp_get_uncompressed_length(pin, (nuint)input.Length, out uint declared, out _) != SnpStatus.Ok) return false;
+                if (declared < (uint)MinGpuDecompressBytes) return false;
+            }
+        }
+        return GpuContext.IsAvailable;
+    }
+
     /// <summary>Snappy.GetMaxCompressedLength (Snappy.cs:20-24).</summary>
     public static int GetMaxCompressedLength(int inputLength)
     {
@@ -29,6 +61,7 @@ public static unsafe class Snappy
     public static bool TryCompress(ReadOnlySpan<byte> input, Span<byte> output, out int bytesWritten)
     {
         bytesWritten = 0;
+        if (!UseGpuForCompress(input.Length)) return global::Snappier.Snappy.TryCompress(input, output, out bytesWritten);
         if (output.IsEmpty) return false;                                        // Snappy.cs:57-62
         fixed (byte* pin = input)
         fixed (byte* pout = output)
@@ -64,19 +97,21 @@ public static unsafe class Snappy
         return owner.Memory.ToArray();
     }
 
-    /// <summary>Snappy.Compress(ReadOnlySequence, IBufferWriter) (Snappy.cs:82-89): segments are gathered, then one call.</summary>
+    /// <summary>Snappy.Compress(ReadOnlySequence, IBufferWriter) (Snappy.cs:82-89).  The segments are pinned where they lie and
+    /// uploaded one after the other by snp_try_compress_segments: the sequence is never flattened on the managed side.</summary>
     public static void Compress(ReadOnlySequence<byte> input, IBufferWriter<byte> output)
     {
         ArgumentNullException.ThrowIfNull(output);
-        byte[] flat = ArrayPool<byte>.Shared.Rent(checked((int)input.Length));
-        try
-        {
-            input.CopyTo(flat);
-            int max = GetMaxCompressedLength((int)input.Length);
-            int written = Compress(flat.AsSpan(0, (int)input.Length), output.GetSpan(max));
-            output.Advance(written);
-        }
-        finally { ArrayPool<byte>.Shared.Return(flat); }
+        if (!UseGpuForCompress(input.Length)) { global::Snappier.Snappy.Compress(input, output); return; }
+        int max = GetMaxCompressedLength(checked((int)input.Length));
+        Span<byte> dest = output.GetSpan(max);
+        SnpStatus st;
+        nuint written;
+        using (var segs = new PinnedSegments(input))
+        fixed (byte* pout = dest)
+            st = NativeMethods.snp_try_compress_segments(GpuContext.Current.Handle, segs.Pointers, segs.Lengths, (uint)segs.Count, pout, (nuint)dest.Length, out written);
+        ThrowIfFailed(st);
+        output.Advance(checked((int)written));
     }
 
     /// <summary>Snappy.GetUncompressedLength (Snappy.cs:142-143): InvalidDataException("Invalid stream length") on a bad preamble.</summary>
@@ -103,6 +138,7 @@ public static unsafe class Snappy
     public static bool TryDecompress(ReadOnlySpan<byte> input, Span<byte> output, out int bytesWritten)
     {
         bytesWritten = 0;
+        if (!UseGpuForDecompress(input)) return global::Snappier.Snappy.TryDecompress(input, output, out bytesWritten);
         fixed (byte* pin = input)
         fixed (byte* pout = output)
         {
@@ -134,17 +170,32 @@ public static unsafe class Snappy
         }
     }
 
-    /// <summary>Snappy.DecompressToMemory(ReadOnlySequence) (Snappy.cs:246-262).</summary>
+    /// <summary>Snappy.DecompressToMemory(ReadOnlySequence) (Snappy.cs:246-262): segments pinned in place, snp_try_decompress_segments.</summary>
     public static IMemoryOwner<byte> DecompressToMemory(ReadOnlySequence<byte> input)
     {
         if (input.IsSingleSegment) return DecompressToMemory(input.FirstSpan);
-        byte[] flat = ArrayPool<byte>.Shared.Rent(checked((int)input.Length));
+        Span<byte> head = stackalloc byte[NativeMethods.VarintMax];
+        int headLen = (int)Math.Min(input.Length, head.Length);
+        input.Slice(0, headLen).CopyTo(head);
+        int length = GetUncompressedLength(head.Slice(0, headLen));              // InvalidDataException on a bad preamble
+        if (length < MinGpuDecompressBytes || !GpuContext.IsAvailable) return global::Snappier.Snappy.DecompressToMemory(input);
+        byte[] buffer = ArrayPool<byte>.Shared.Rent(Math.Max(length, 1));
         try
         {
-            input.CopyTo(flat);
-            return DecompressToMemory(flat.AsSpan(0, (int)input.Length));
+            SnpStatus st;
+            nuint written;
+            using (var segs = new PinnedSegments(input))
+            fixed (byte* pout = buffer)
+                st = NativeMethods.snp_try_decompress_segments(GpuContext.Current.Handle, segs.Pointers, segs.Lengths, (uint)segs.Count, pout, (nuint)length, out written);
+            ThrowIfFailed(st);
+            if ((int)written != length) throw new InvalidDataException("Incomplete Snappy block.");      // Snappy.cs:229-232
+            return new PooledOwner(buffer, length);
         }
-        finally { ArrayPool<byte>.Shared.Return(flat); }
+        catch
+        {
+            ArrayPool<byte>.Shared.Return(buffer);
+            throw;
+        }
     }
 
     /// <summary>Snappy.Decompress(ReadOnlySequence, IBufferWriter) (Snappy.cs:194-212).</summary>
@@ -180,6 +231,40 @@ public static unsafe class Snappy
             case SnpStatus.TruncatedStream: throw new InvalidDataException(NativeMethods.StatusString(st));
             case SnpStatus.BadArg: throw new ArgumentException(NativeMethods.StatusString(st));
             default: throw new InvalidOperationException("libsnappier_hip: " + NativeMethods.StatusString(st) + " " + (GpuContext.TryGetCurrent(out GpuContext? c) ? c!.LastError : string.Empty));
+        }
+    }
+
+    /// <summary>The segments of a ReadOnlySequence pinned for the duration of one native call: pointer and length arrays in
+    /// unmanaged memory (what snp_try_*_segments takes), one MemoryHandle per segment.</summary>
+    private sealed class PinnedSegments : IDisposable
+    {
+        private readonly MemoryHandle[] _handles;
+        private readonly IntPtr _block;
+        public int Count { get; }
+        public byte** Pointers => (byte**)_block;
+        public nuint* Lengths => (nuint*)((byte*)_block + Count * sizeof(IntPtr));
+
+        public PinnedSegments(ReadOnlySequence<byte> input)
+        {
+            int n = 0;
+            foreach (ReadOnlyMemory<byte> _ in input) ++n;
+            Count = n;
+            _handles = new MemoryHandle[n];
+            _block = System.Runtime.InteropServices.Marshal.AllocHGlobal(Math.Max(1, n) * (sizeof(IntPtr) + sizeof(nuint)));
+            int i = 0;
+            foreach (ReadOnlyMemory<byte> m in input)
+            {
+                _handles[i] = m.Pin();
+                Pointers[i] = (byte*)_handles[i].Pointer;
+                Lengths[i] = (nuint)m.Length;
+                ++i;
+            }
+        }
+
+        public void Dispose()
+        {
+            foreach (MemoryHandle h in _handles) h.Dispose();
+            System.Runtime.InteropServices.Marshal.FreeHGlobal(_block);
         }
     }
 

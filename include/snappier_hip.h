@@ -145,6 +145,15 @@ snp_status snp_try_compress(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* 
  * SnappyDecompressor.cs:43-92,184-347.  One whole Snappy block of any declared length. */
 snp_status snp_try_decompress(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written);
 
+/* The same two calls for an input that arrives in SEGMENTS -- Snappy.Compress(ReadOnlySequence<byte>, IBufferWriter<byte>) and
+ * Snappy.Decompress / DecompressToMemory(ReadOnlySequence<byte>)  Snappy.cs:82-89,194-212,246-262: the concatenation of the nseg host
+ * segments is ONE input (one Snappy block); each segment is uploaded straight from where it lies (pinned by the caller for the
+ * duration of the call), so the managed side does not flatten the sequence first.  Same results and status codes as the span forms. */
+snp_status snp_try_compress_segments(snp_ctx* ctx, const uint8_t* const* seg, const size_t* seg_len, uint32_t nseg,
+                                     uint8_t* out, size_t cap, size_t* written);
+snp_status snp_try_decompress_segments(snp_ctx* ctx, const uint8_t* const* seg, const size_t* seg_len, uint32_t nseg,
+                                       uint8_t* out, size_t cap, size_t* written);
+
 /* Crc32CAlgorithm.Compute + ApplyMask  Crc32CAlgorithm.cs:41-49,156-158. masked != 0 applies the framing mask. */
 snp_status snp_crc32c(snp_ctx* ctx, const uint8_t* in, size_t n, int masked, uint32_t* out_crc);
 

@@ -35,9 +35,9 @@ if mode == "chains":
              "A + overrun trips (wave max)", "chains walked on by the wave", "tags of those walks", "lanes on the true chain"]
     for k, nme in enumerate(names):
         print(f"chains: {nme:34s} {buf[k]/nb:12.1f} per block")
-tn = ["stage input", "chains, merge, tag list", "tag bytes, decode, scan, first pass", "extra pass", "serial finish + write-out"] if mode == "chains" else ["wait input window", "parse (decode, chain, scan, enqueue)", "first pass", "extra pass", "serial finish"] if mode == "queued" else \
+tn = ["stage input", "chains, merge, tag list", "batch top wait + decode + scan + checks", "first pass (loads, stage stores)", "second pass + in-order finish", "write-out + store acknowledgement"] if mode == "chains" else ["wait input window", "parse (decode, chain, scan, enqueue)", "first pass", "extra pass", "serial finish"] if mode == "queued" else \
      ["wait input window", "tag decode + next ptrs", "chain walk", "prefix sum + checks", "copies (all rounds)"]
-tot = sum(buf[10:15])
+tot = sum(buf[10:16])
 for k, nme in enumerate(tn):
     print(f"{nme:38s} {buf[10+k]/nb:12.0f} cycles per block {100*buf[10+k]/max(tot,1):5.1f}%")
 print("rounds per batch", buf[3] / max(buf[0], 1), " tags per batch", buf[1] / max(buf[0], 1))

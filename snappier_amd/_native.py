@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
         "snp_get_uncompressed_length": (i32, [vp, sz, C.POINTER(u32), C.POINTER(u32)]),
         "snp_try_compress": (i32, [vp, vp, sz, vp, sz, szp]),
         "snp_try_decompress": (i32, [vp, vp, sz, vp, sz, szp]),
+        "snp_try_compress_segments": (i32, [vp, C.POINTER(vp), szp, u32, vp, sz, szp]),
+        "snp_try_decompress_segments": (i32, [vp, C.POINTER(vp), szp, u32, vp, sz, szp]),
         "snp_crc32c": (i32, [vp, vp, sz, i32, C.POINTER(u32)]),
         "snp_frame_max_encoded_length": (i64, [i64]),
         "snp_frame_encode": (i32, [vp, vp, sz, vp, sz, szp]),

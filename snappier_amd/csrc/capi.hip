@@ -802,13 +802,51 @@ static bool ranges_overlap(const u8* a, size_t an, const u8* b, size_t bn)
     return an && bn && a < b + bn && b < a + an;
 }
 
-snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written)
+}  // extern "C"
+
+namespace {
+// The input of a host-pointer call: one span (snp_try_compress / snp_try_decompress) or the segments of a ReadOnlySequence
+// (snp_try_*_segments).  Segments go up one after the other into ONE device buffer: the managed side never flattens them.
+struct HostSpans {
+    const uint8_t* const* ptr;
+    const size_t* len;
+    uint32_t count;
+    bool valid(size_t* total) const
+    {
+        size_t t = 0;
+        for (uint32_t i = 0; i < count; ++i) {
+            if (len[i] && !ptr[i]) return false;
+            if (len[i] > 0xffffffffull || t + len[i] > 0xffffffffull) { *total = ~size_t{0}; return true; }
+            t += len[i];
+        }
+        *total = t;
+        return true;
+    }
+    bool upload(snp_ctx* c, void* dev) const
+    {
+        size_t at = 0;
+        for (uint32_t i = 0; i < count; ++i) {
+            if (len[i] && !c->h2d(static_cast<u8*>(dev) + at, ptr[i], len[i], "H2D input segment")) return false;
+            at += len[i];
+        }
+        return true;
+    }
+    void head(uint8_t* dst, size_t want) const                            // the first `want` bytes (the varint preamble)
+    {
+        size_t got = 0;
+        for (uint32_t i = 0; i < count && got < want; ++i)
+            for (size_t k = 0; k < len[i] && got < want; ++k) dst[got++] = ptr[i][k];
+    }
+};
+
+snp_status compress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uint8_t* out, size_t cap, size_t* written)
 {
-    if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    const uint8_t* in = in_spans.count == 1 ? in_spans.ptr[0] : nullptr;
     *written = 0;
     if (n > 0xffffffffull) return SNP_ERR_BAD_ARG;                       // SnappyCompressor.cs:88-91
     if (cap == 0) return SNP_ERR_OUTPUT_TOO_SMALL;                        // Snappy.cs:57-62
-    if (ranges_overlap(in, n, out, cap)) return SNP_ERR_OVERLAP;          // SnappyCompressor.cs:27-30
+    for (uint32_t i = 0; i < in_spans.count; ++i)
+        if (ranges_overlap(in_spans.ptr[i], in_spans.len[i], out, cap)) return SNP_ERR_OVERLAP;   // SnappyCompressor.cs:27-30
     DevGuard dg(c);
     if (!dg.ok) return SNP_ERR_DEVICE;
 
@@ -837,7 +875,11 @@ snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
     i32* d_status = reinterpret_cast<i32*>(d_comp_len + nf);
 
     bool ok = c->check(snp_launch_frame_chunks(n, nf, kCompStride, d_in_off, d_in_len, d_comp_off, s), "fragment table");
-    ok = ok && c->upload_and_compress(in, n, nf, d_in_off, d_in_len, static_cast<u8*>(c->work.p), d_comp_off, d_comp_len, d_status, 0);
+    if (in)
+        ok = ok && c->upload_and_compress(in, n, nf, d_in_off, d_in_len, static_cast<u8*>(c->work.p), d_comp_off, d_comp_len, d_status, 0);
+    else
+        ok = ok && in_spans.upload(c, c->in.p) &&
+             c->launch_compress(static_cast<const u8*>(c->in.p), d_in_off, d_in_len, nf, static_cast<u8*>(c->work.p), d_comp_off, d_comp_len, d_status, 0);
     std::vector<u32> comp_len(nf);
     ok = ok && c->check(hipMemcpyAsync(comp_len.data(), d_comp_len, nf * 4ull, hipMemcpyDeviceToHost, s), "D2H lengths");
     ok = ok && c->check(hipStreamSynchronize(s), "sync");
@@ -859,11 +901,12 @@ snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* ou
     return SNP_OK;
 }
 
-snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written)
+snp_status decompress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uint8_t* out, size_t cap, size_t* written)
 {
-    if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
     *written = 0;
     if (n > 0x7fffffffull) return SNP_ERR_BAD_ARG;                        // the reference's spans are int-length
+    uint8_t in[8] = {0};                                                  // the preamble is read on the host
+    in_spans.head(in, n < 5 ? n : 5);
     DevGuard dg(c);
     if (!dg.ok) return SNP_ERR_DEVICE;
     hipStream_t s = c->stream;
@@ -874,7 +917,7 @@ snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* 
     struct Meta { u64 in_off, out_off; u32 in_len, out_cap, out_len; i32 status; } h{0, 0, static_cast<u32>(n), cap32, 0, 0};
     u8* m = static_cast<u8*>(c->meta.p);
     bool ok = c->check(hipMemcpyAsync(m, &h, sizeof(h), hipMemcpyHostToDevice, s), "H2D meta");
-    if (n) ok = ok && c->h2d(c->in.p, in, n, "H2D input");
+    if (n) ok = ok && in_spans.upload(c, c->in.p);
 
     // A large block: one wavefront per 64 KiB output fragment, fragment starts from the tag index (tag_index.hip).
     // Taken only for a clean preamble that fits the output; any fragment that does not come back OK (foreign streams
@@ -960,6 +1003,46 @@ snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* 
     }
     *written = h.out_len;
     return SNP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+snp_status snp_try_compress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written)
+{
+    if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    const HostSpans one{&in, &n, 1};
+    return compress_spans(c, one, n, out, cap, written);
+}
+
+snp_status snp_try_decompress(snp_ctx* c, const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written)
+{
+    if (!c || !written || (n && !in) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    const HostSpans one{&in, &n, 1};
+    return decompress_spans(c, one, n, out, cap, written);
+}
+
+snp_status snp_try_compress_segments(snp_ctx* c, const uint8_t* const* seg, const size_t* seg_len, uint32_t nseg, uint8_t* out, size_t cap,
+                                     size_t* written)
+{
+    if (!c || !written || (nseg && (!seg || !seg_len)) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    *written = 0;
+    const HostSpans spans{seg, seg_len, nseg};
+    size_t n = 0;
+    if (!spans.valid(&n)) return SNP_ERR_BAD_ARG;
+    if (n == ~size_t{0}) return SNP_ERR_BAD_ARG;                          // >= 2^32 bytes in all  SnappyCompressor.cs:88-91
+    return compress_spans(c, spans, n, out, cap, written);
+}
+
+snp_status snp_try_decompress_segments(snp_ctx* c, const uint8_t* const* seg, const size_t* seg_len, uint32_t nseg, uint8_t* out, size_t cap,
+                                       size_t* written)
+{
+    if (!c || !written || (nseg && (!seg || !seg_len)) || (cap && !out)) return SNP_ERR_BAD_ARG;
+    *written = 0;
+    const HostSpans spans{seg, seg_len, nseg};
+    size_t n = 0;
+    if (!spans.valid(&n) || n == ~size_t{0}) return SNP_ERR_BAD_ARG;
+    return decompress_spans(c, spans, n, out, cap, written);
 }
 
 snp_status snp_crc32c(snp_ctx* c, const uint8_t* in, size_t n, int masked, uint32_t* out_crc)

@@ -40,24 +40,13 @@ constexpr u32 crc_step32(u32 x)
 // fragment's first four bytes kept in a register.  Results are unchanged: "check bits differ" implies "bytes differ".
 __device__ __forceinline__ u32 check_bits(u32 bytes) { return (bytes * 0x9E3779B1u) & 0xffff0000u; }
 
-// Table accesses under a cache policy chosen per launch (round-3 experiments, option bits 5 and 6 of lit_blind):
-//   nt   -- non-temporal load / store: the table sectors are touched once per ~1 000 probes of the same lane, so they should
-//           not displace the INPUT lines (64 lanes x ~128 live bytes per wavefront) from L2;
-//   swap -- `cand = table[h]; table[h] = ip` (SnappyCompressor.cs:329-333) IS an exchange: one global_atomic_swap (executed at L2,
-//           one request) instead of a load and a store (two requests, the store a read-for-ownership of the same sector).
-// (NT is a template parameter: selected at run time the two loads fold into one plain load and the hint is lost)
-template <bool NT>
-__device__ __forceinline__ u32 table_load(const u32* p)
-{
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-template <bool NT>
-__device__ __forceinline__ void table_store(u32* p, u32 v)
-{
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
+// Probe + insert as ONE memory request.  `cand = table[h]; table[h] = ip` (SnappyCompressor.cs:329-333) IS an exchange: one
+// global_atomic_swap (executed at L2) instead of a load and a store, the store being a read-for-ownership of the same sector.
+// Round 3, same-process A/B on one workspace: 123.0 -> 112.8 ms per 10 GiB of html-like blocks, mixed corpus 174.0 -> 161.1
+// (profiles/r03a_compress_option_ab.json, r03b_compress_option_ab_*.json).  Measured with it and rejected: non-temporal table loads /
+// stores (148.3 ms: the two halves of a read-modify-write want the sector to stay in L2 in between) and a 16-byte register window
+// over the input (one input load per ~9 probes: 121.2 ms alone, 112.4 with the exchange -- input requests hit L1 / L2 and are nearly
+// free at the table-rate bound); both were removed again.
 __device__ __forceinline__ u32 table_swap(u32* p, u32 v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct LaneCtx {
@@ -221,7 +210,7 @@ __device__ __forceinline__ void stage_drain(const LaneCtx& c, OutStage& st, u32 
     st.flushed = op;
 }
 
-template <int VARIANT, u32 kSlots, bool NT>
+template <int VARIANT, u32 kSlots>
 __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                             const u32* __restrict__ in_len, u32 nblocks,
                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
@@ -254,7 +243,6 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     if (b >= nblocks) return;
     const bool staged = (lit_blind & 16) != 0;
     const bool t_swap = kSlots == 1 && (lit_blind & 64) != 0;          // probe + insert as one atomic exchange (one probe per trip only)
-    bool in_win = (lit_blind & 128) != 0;                              // 16-byte register window over the input for the probe bytes (n >= 32, set below)
     OutStage stg{s_out + threadIdx.x * kStageStride, 0};
 
     LaneCtx c;
@@ -265,7 +253,6 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     const u32 n = c.n;
     c.first4 = n >= 4 ? ld32u(c.src) : 0u;
     if (n > SNP_BLOCK_SIZE) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; return; }
-    in_win = in_win && n >= 32;
 
     u32 op = 0;
     if (emit_varint) {                                                 // VarIntEncoding.TryWrite  VarIntEncoding.Write.cs:5-79
@@ -284,8 +271,6 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     enum : u32 { kScan = 0, kPost = 1, kExtend = 2, kDone = 3 };
     u32 mode = kDone;
     u32 next_emit = 0, skip = 32, cand = 0, base = 0, mlen = 0, limit = 0;
-    snp_u128_unaligned win = {};                                       // option bit 7: input bytes [win_at, win_at + 16)
-    u32 win_at = 0x80000000u;
     if (n >= 15) {                                                     // :190
         const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << (31u - __clz(n - 1)));   // HashTable.cs:57-71
         c.mask = 2 * (tsize - 1);                                      // :181
@@ -327,25 +312,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 legal[k] = ok;
                 q = nx[k];
             }
-            const u32 at = ip - (post ? 1u : 0u);                       // ip <= limit = n - 15: in bounds
-            if (in_win) {
-                // the 8 probe bytes come out of a 16-byte register window that is reloaded when the scan leaves it: a stride-1 scan
-                // asks memory for input once per 9 probes instead of once per probe
-                u32 o = at - win_at;
-                if (o > 8u) {
-                    win_at = min(at, n - 16u);                          // at <= limit = n - 15: the window is pulled back inside the fragment
-                    win = *reinterpret_cast<const snp_u128_unaligned*>(c.src + win_at);
-                    o = at - win_at;                                    // 0 or 1
-                }
-                const u32 dq = o >> 2, sh = (o & 3u) * 8u;
-                const u32 a0 = dq == 0 ? win.v[0] : dq == 1 ? win.v[1] : win.v[2];
-                const u32 a1 = dq == 0 ? win.v[1] : dq == 1 ? win.v[2] : win.v[3];
-                const u32 a2 = dq == 0 ? win.v[2] : dq == 1 ? win.v[3] : 0u;
-                const u64 lo = (static_cast<u64>(a1) << 32) | a0;
-                w0 = sh ? (lo >> sh) | (static_cast<u64>(a2) << (64u - sh)) : lo;
-            } else {
-                w0 = ld64u(c.src + at);
-            }
+            w0 = ld64u(c.src + ip - (post ? 1u : 0u));                  // ip <= limit = n - 15: in bounds
         } else {
 #pragma unroll
             for (u32 k = 0; k < kSlots; ++k) { p[k] = nx[k] = sk[k] = 0; legal[k] = false; }
@@ -372,7 +339,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 const u32 dm1 = static_cast<u32>(w0);
                 hm1 = lane_hash<VARIANT>(c, dm1, lut);
                 vm1 = (ip - 1) | check_bits(dm1);
-                table_store<NT>(&c.table[hm1], vm1);
+                c.table[hm1] = vm1;
                 d[0] = static_cast<u32>(w0 >> 8);
             } else {
                 d[0] = static_cast<u32>(w0);
@@ -394,7 +361,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 cv[0] = !legal[0] ? 0u : swapped ? table_swap(&c.table[h[0]], p[0] | check_bits(d[0])) : vm1;
             } else {
 #pragma unroll
-                for (u32 k = 0; k < kSlots; ++k) cv[k] = legal[k] ? table_load<NT>(&c.table[h[k]]) : 0u;   // :329 / :396  (position | check bits)
+                for (u32 k = 0; k < kSlots; ++k) cv[k] = legal[k] ? c.table[h[k]] : 0u;   // :329 / :396  (position | check bits)
             }
         }
         // ---- extension: compare what trip 1 brought (while the table entries are in flight) -----------------------
@@ -464,7 +431,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                     if (!legal[k]) {
                         if (!post) { ended = true; ip = next_emit; mode = kDone; }   // :323-327 -> emit_remainder
                     } else if (!swapped) {
-                        table_store<NT>(&c.table[h[k]], p[k] | check_bits(d[k]));   // :333 / :397
+                        c.table[h[k]] = p[k] | check_bits(d[k]);   // :333 / :397
                     }
                 }
             }
@@ -635,6 +602,19 @@ extern "C" hipError_t snp_probe_tables(void* tables, u32 nblocks, hipStream_t st
     return e;
 }
 
+// test hook (include/snappier_hip_debug.h): FindMatchLength as this kernel's lanes compute it, driven with the reference's KATs
+namespace {
+__global__ void k_debug_lane_match_length(const u8* buf, u32 n, u32 s1, u32 s2, u32* out)
+{
+    if (threadIdx.x == 0) *out = lane_find_match_length(buf, s1, s2, n);
+}
+}  // namespace
+extern "C" int snp_debug_lane_match_length(const u8* d_buf, u32 n, u32 s1, u32 s2, u32* d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_debug_lane_match_length, dim3(1), dim3(SNP_WAVE), 0, stream, d_buf, n, s1, s2, d_out);
+    return static_cast<int>(hipGetLastError());
+}
+
 extern "C" size_t snp_compress_lanes_workspace(u32 nblocks) { return static_cast<size_t>(nblocks) * 16384u * sizeof(u32); }
 
 // longest fragment of the batch, on the device (the host never sees the lengths of a device-resident batch)
@@ -663,24 +643,23 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const u32 grid = (nblocks + per - 1) / per;
     // Output-store options (bit 0: a short literal may overshoot with one 16-byte store, bit 1: tag + body of a literal in
     // one store, bit 2: a copy tag as one 4-byte store, bit 3: 16- instead of 32-byte extension trips, bit 4: output staged
-    // in LDS and written as whole 64-byte runs; default 1+2+4+16).  SNAPPIER_HIP_EXACT_LITERALS=1 = none (exact-length stores only);
+    // in LDS and written as whole 64-byte runs, bit 6: probe + insert as one atomic exchange (table_swap, one-probe-per-trip launches); default
+    // 1+2+4+16+64).  SNAPPIER_HIP_EXACT_LITERALS=1 = none (exact-length stores only);
     // SNAPPIER_HIP_CL_OPTS=<mask> picks a subset -- read per launch, so one process can A/B on the same workspace.
     const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");
     const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
     // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
-    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : (nblocks >= 32768 ? 23 : 7);
+    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 127) : ((nblocks >= 32768 ? 23 : 7) | 64);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
     // one probe is 1.5 % faster at 163 840)
     const u32 slots = se ? static_cast<u32>(atoi(se)) : (nblocks >= 131072 ? kDefaultSlots : 2u);
-#define SNP_LAUNCH_CL(V, S, T)                                                                                       \
-    hipLaunchKernelGGL((k_compress_lanes<V, S, T>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out, \
+#define SNP_LAUNCH_CL(V, S)                                                                                          \
+    hipLaunchKernelGGL((k_compress_lanes<V, S>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
                        out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind, max_len)
-#define SNP_LAUNCH_CL2(V, S) do { if (lit_blind & 32) SNP_LAUNCH_CL(V, S, true); else SNP_LAUNCH_CL(V, S, false); } while (0)
-    if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL2(SNP_HASH_CRC32C, 1); else SNP_LAUNCH_CL2(SNP_HASH_CRC32C, 2); }
-    else { if (slots == 1) SNP_LAUNCH_CL2(SNP_HASH_MUL, 1); else SNP_LAUNCH_CL2(SNP_HASH_MUL, 2); }
-#undef SNP_LAUNCH_CL2
+    if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 1); else SNP_LAUNCH_CL(SNP_HASH_CRC32C, 2); }
+    else { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_MUL, 1); else SNP_LAUNCH_CL(SNP_HASH_MUL, 2); }
 #undef SNP_LAUNCH_CL
     return hipGetLastError();
 }

@@ -765,7 +765,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
     }
 }
 
-// test hook: FindMatchLength by the wave, as the kernel uses it (tests/test_gpu_parity.py runs the reference's KATs through it)
+// test hook (include/snappier_hip_debug.h): FindMatchLength by the wave, as the kernel uses it (tests/test_gpu_parity.py runs the reference's KATs through it)
 __global__ __launch_bounds__(SNP_WAVE) void k_debug_match_length(const u8* buf, u32 n, u32 p, u32 cand, u32 known, u32* out)
 {
     const u32 r = wave_match_extend(buf, n, p, cand, known, lane_id());

@@ -145,39 +145,11 @@ __device__ __forceinline__ void st128u(u8* p, u32x4 v)
     t.v[0] = v.x; t.v[1] = v.y; t.v[2] = v.z; t.v[3] = v.w;
     *reinterpret_cast<snp_u128_unaligned*>(p) = t;
 }
-#ifndef SNP_D_NT
-#define SNP_D_NT 0          // sub-chain front end: 1 = the compressed stream (super-window staging, tag bytes) is read with non-temporal loads
-#endif                      // (read once: it should not displace the output lines that back-references re-read from L2)
-typedef u32 u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
-typedef u32 u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
-__device__ __forceinline__ u32x4 ld128u_in(const u8* p)
-{
-#if SNP_D_NT
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4_a1*>(p));
-#else
-    return ld128u(p);
-#endif
-}
-__device__ __forceinline__ u64 ld64u_in(const u8* p)
-{
-#if SNP_D_NT
-    const u32x2_a1 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a1*>(p));
-    return (static_cast<u64>(t.y) << 32) | t.x;
-#else
-    return ld64u(p);
-#endif
-}
 // One lane copies len (1..64) bytes, requesting its pieces in pairs: head + tail first (every copy of <= 32 bytes is one round
 // trip), then the two middle pieces of a longer one.
-#ifndef SNP_D_QLIT
-#define SNP_D_QLIT 0        // sub-chain front end: 1 = a literal of <= 7 bytes is cut out of the 8 tag bytes the lane already holds (no source load)
-#endif
-template <bool HAVE_Q = false>
-__device__ __forceinline__ void lane_copy2(u8* d, const u8* s, u32 len, bool use_q = false, u64 qbytes = 0)
+__device__ __forceinline__ void lane_copy2(u8* d, const u8* s, u32 len)
 {
-    u32x4 p0;
-    if (HAVE_Q && use_q) p0 = u32x4{static_cast<u32>(qbytes), static_cast<u32>(qbytes >> 32), 0u, 0u};
-    else p0 = ld128u(s);
+    const u32x4 p0 = ld128u(s);
     u32x4 p1;                                                           // read only where it was loaded
     if (len > 16) p1 = ld128u(s + len - 16);
 #if SNP_D_PIECES == 4
@@ -260,15 +232,6 @@ __device__ __forceinline__ u64 lds_ld64u(const u8* p) { return reinterpret_cast<
 // DS operations of one wavefront execute in order; this only stops the compiler from reordering or forwarding them.
 __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory"); }
 
-#ifndef SNP_D_V4
-#define SNP_D_V4 1          // sub-chain front end, round 3: staged input kept in LDS, tag list in registers, aligned write-out (0: the round-2 form)
-#endif
-#ifndef SNP_D_HOIST
-#define SNP_D_HOIST 1       // SNP_D_V4: build the second pass's pending-output bitmap while the first pass's source loads are in flight
-#endif
-#ifndef SNP_D_ALIGNED_OUT
-#define SNP_D_ALIGNED_OUT 1 // SNP_D_V4: write-out on 16-byte boundaries of the address, remainder carried in the stage (0: every batch written out whole)
-#endif
 #ifndef SNP_D_ABLATE
 #define SNP_D_ABLATE 0      // TIMING-ONLY ablations of the sub-chain front end (the output is wrong): 1 no first-pass copies, 2 no serial finish,
 #endif                      // 4 no write-out, 16 no second pass, 32 tag lists only (no batches), 64 first-pass copy sources pulled to within 1 KiB (no far reads)
@@ -295,7 +258,7 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #if SNP_D_PROF
 __device__ unsigned long long g_dprof[16];
 #define DPROF_ADD(k, v) do { if (lane == 0 && ((k) >= 10 || SNP_D_PROF == 2)) atomicAdd(&g_dprof[k], static_cast<unsigned long long>(v)); } while (0)
-#define DPROF_T0 u64 dprof_t = __builtin_readcyclecounter(); u64 dprof_acc[5] = {0, 0, 0, 0, 0};
+#define DPROF_T0 u64 dprof_t = __builtin_readcyclecounter(); u64 dprof_acc[6] = {0, 0, 0, 0, 0, 0};
 #define DPROF_TIME(k)                                                             \
     do {                                                                          \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
@@ -303,7 +266,7 @@ __device__ unsigned long long g_dprof[16];
         dprof_acc[(k) - 10] += now_ - dprof_t;                                    \
         dprof_t = now_;                                                           \
     } while (0)
-#define DPROF_FLUSH do { for (int k_ = 0; k_ < 5; ++k_) DPROF_ADD(10 + k_, dprof_acc[k_]); } while (0)
+#define DPROF_FLUSH do { for (int k_ = 0; k_ < 6; ++k_) DPROF_ADD(10 + k_, dprof_acc[k_]); } while (0)
 #define DPROF_TRIP(v) ++(v)
 #define DPROF_ADD_MAX(k, v)                                                                          \
     do {                                                                                             \
@@ -857,458 +820,6 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
     // prefix sum of the output lengths -> the staged batch of the queued front end (assembled in LDS, written out coalesced).
     // A batch ends before the first tag it cannot take (malformed, a literal > 64 bytes, the last 16 output bytes): a long
     // literal is copied by the whole wave and parsing goes on; anything else falls to the serial loop below.
-#if SNP_D_V4
-    // Round 3 (SNP_D_V4): the same parse, but the staged input STAYS in LDS for the whole super-window --
-    //   * the tag list goes through the (idle) stage into REGISTERS: entry t sits in lane t % 64, slot t / 64 (eight VGPRs of two
-    //     u16 each, shifted down by one entry whenever a slot is used up); batches are slot-aligned (lane l executes tag
-    //     64 s + l; after a batch that ended early the next one runs the slot's remaining lanes), so no lane ever needs another
-    //     lane's entry;
-    //   * a tag's bytes are two aligned LDS dwords (no 8-byte global gather per batch, nothing to prefetch), a literal's body
-    //     comes from LDS too (<= 4 bytes: out of those two dwords): the only global loads of a batch are the sources of copies;
-    //   * the source loads of the first pass are REQUESTED, then the pending-output bitmap of the second pass is built while
-    //     they are in flight, then their bytes go to the stage;
-    //   * the write-out is 16-byte aligned: the stage holds the output from `mark_g` (a 16-byte boundary of the ADDRESS) on,
-    //     whole 16-byte chunks leave, the < 16 bytes behind them are carried to the front of the stage for the next batch --
-    //     no byte-tail store, no store that straddles a sector; a copy that reads carried bytes finds them in the stage.
-    if (FRONT == 3) {
-        constexpr u32 kR = 32;                                          // input bytes per lane region
-        constexpr u32 kW = SNP_WAVE * kR;                               // the super-window
-        constexpr u32 kCap = 128;                                       // a chain may overrun its region by this much before the wave takes over
-        constexpr u32 kPad = 128;                                       // staged behind the super-window: the body of a literal whose tag starts inside it (+ 15 over-read)
-        __shared__ __attribute__((aligned(16))) u8 c_in[kW + kPad];
-        __shared__ __attribute__((aligned(16))) u8 c_stage[SNP_D_STAGE + 128];
-        __shared__ u64 c_busy[65];                                      // batches: pending output bytes; while a super-window is built: V and T
-        u32* const c_V = reinterpret_cast<u32*>(c_busy);
-        u32* const c_T = c_V + SNP_WAVE;
-        u8* const c_scr = c_stage + 16;                                 // scratch while a super-window is built (the first 16 bytes of the stage hold the carry)
-        u16* const c_list = reinterpret_cast<u16*>(c_scr);
-        const u32 r0 = kR * lane;
-        const u32 a0 = static_cast<u32>(reinterpret_cast<uintptr_t>(dst)) & 15u;
-        u32 wbase = ip, ntok = 0, emitted = 0, consumed = 0;
-        u32 mark_g = op;                                                // output below it is in global memory; [mark_g, op) is stage[0 .. op - mark_g)
-        u32 l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;   // this lane's 16 list entries, the current slot's in the low half of l0
-        // the carried bytes go out (byte stores) before anything writes the output around the stage
-#define SNP_D_FLUSH_CARRY()                                                                      \
-        do {                                                                                     \
-            if (lane < op - mark_g) dst[mark_g + lane] = c_stage[lane];                          \
-            mark_g = op;                                                                         \
-        } while (0)
-        DPROF_T0
-        while (st == SNP_OK) {
-            if (emitted == ntok) {
-                // ---- the next super-window ----
-                ip = wbase + consumed;
-                if (ip + 72 > n || op >= expected) break;
-                wbase = ip;
-                const u32 avail = n - wbase;
-                const u32 L = min(kW, avail - 8u);                      // tags may start below L: their 8 bytes lie inside the staged input
-                const u8* const wsrc = src + wbase;
-                {
-                    // 16 bytes per lane, twice, + 128 bytes of padding; a piece that would cross the end of the input is pulled back
-                    // inside it (avail >= 72; the bytes it rewrites are the same bytes), pieces beyond it are not needed
-                    const u32 oa = lane * 16u, ob = oa + 1024u, oc = oa + 2048u;
-                    const u32 la = min(oa, avail - 16u), lb = min(ob, avail - 16u), lc = min(oc, avail - 16u);
-                    const u32x4 va = ld128u_in(wsrc + la), vb = ld128u_in(wsrc + lb);
-                    st128u(c_in + la, va);
-                    st128u(c_in + lb, vb);
-                    if (lane < kPad / 16u) st128u(c_in + lc, ld128u_in(wsrc + lc));
-                }
-                lanes_sync_lds();
-                DPROF_TIME(10);                                         // input staged
-                // A: the chain from the first byte of the lane's region
-                u32 p = r0, V = 0;
-                [[maybe_unused]] u32 trips = 0;
-                {
-                    const u32 lim = min(r0 + kR, L);
-                    while (p < lim) {
-                        V |= 1u << (p - r0);
-                        p += tag_advance_staged(c_in + p);
-                        DPROF_TRIP(trips);
-                    }
-                }
-                DPROF_ADD_MAX(3, trips);                                // loop trips of phase A
-                c_V[lane] = V;
-                c_T[lane] = 0;
-                lanes_sync_lds();
-                // A': on past the region until the chain lands on a position its owner visited
-                u32 nx = 64u;                                           // 64: the chain leaves the super-window, 65: no merge within kCap bytes
-                u32* const c_O = reinterpret_cast<u32*>(c_scr + 512) + lane * (kCap / 32);   // overrun positions, a bit each, from obase
-                {
-                    u32 z = 0;                                          // (a zero the compiler cannot hoist out of the loop: hoisted, the four zero
-                    asm volatile("" : "+v"(z));                         //  registers of this store were SPILLED to scratch to make room)
-#pragma unroll
-                    for (u32 w = 0; w < kCap / 32; ++w) c_O[w] = z;
-                }
-                const u32 obase = p & ~(kR - 1u);
-                for (bool go = p < L; go;) {
-                    const u32 v = c_V[p >> 5];
-                    const u32 adv = tag_advance_staged(c_in + p);
-                    const u32 rel = p - obase;
-                    const bool hit = (v >> (p & 31u)) & 1u;
-                    const bool stop = hit | (rel >= kCap);
-                    nx = stop ? (hit ? p >> 5 : 65u) : nx;
-                    atomicOr(&c_O[min(rel >> 5, kCap / 32 - 1)], stop ? 0u : 1u << (rel & 31u));   // (unconditional: no exec-mask bookkeeping)
-                    p = stop ? p : p + adv;
-                    go = !stop & (p < L);
-                    DPROF_TRIP(trips);
-                }
-                const u32 m = p;                                        // where the chain merged, gave up or left
-                DPROF_ADD_MAX(6, trips);                                // ... of A and A' together
-                // R: the lanes on the true chain = the lanes reachable from lane 0 along nx, by pointer doubling
-                u64 active;
-                u32 entry = 0;
-                {
-                    u8* const c_reach = c_scr;
-                    u32* const c_entry = reinterpret_cast<u32*>(c_scr + SNP_WAVE);
-                    u32 hop = nx;
-                    bool reached = lane == 0;
-                    c_reach[lane] = reached ? 1 : 0;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        lanes_sync_lds();
-                        if (reached && hop < 64u) c_reach[hop] = 1;
-                        lanes_sync_lds();
-                        reached = c_reach[lane] != 0;
-                        const u32 h2 = bperm(hop, hop);
-                        hop = hop < 64u ? h2 : hop;
-                    }
-                    if (reached && nx < 64u) c_entry[nx] = m;
-                    lanes_sync_lds();
-                    if (lane) entry = c_entry[lane];
-                    lanes_sync_lds();
-                    active = ballot64(reached);
-                    const u64 ends = ballot64(reached && nx == 64u);    // the lane whose chain leaves the super-window, if the chain gets there
-                    consumed = ends ? read_lane(m, static_cast<u32>(__builtin_ctzll(ends))) : 0u;
-                }
-                if (ballot64(((active >> lane) & 1ull) && nx == 65u)) {
-                    // a chain on the true path did not merge within kCap bytes (rare): follow the path lane by lane on the scalar unit
-                    active = 0;
-                    entry = 0;
-                    for (u32 k = 0, e = 0;;) {
-                        active |= 1ull << k;
-                        entry = lane == k ? e : entry;
-                        u32 mk = read_lane(m, k), nk = read_lane(nx, k);
-                        if (nk == 65u) {
-                            DPROF_ADD(7, 1);
-                            nk = 64u;
-                            while (mk < L) {
-                                const u32 v = bcast_first(c_V[mk >> 5]);
-                                if ((v >> (mk & 31u)) & 1u) { nk = mk >> 5; break; }
-                                if (lane == 0) atomicOr(&c_T[mk >> 5], 1u << (mk & 31u));
-                                mk += bcast_first(tag_advance_staged(c_in + mk));
-                                DPROF_ADD(8, 1);
-                            }
-                        }
-                        if (nk >= 64u) { consumed = mk; break; }
-                        e = mk;
-                        k = nk;
-                    }
-                }
-                // T: the true tag starts
-                if ((active >> lane) & 1ull) {
-                    const u32 own = V & ~((1u << (entry & 31u)) - 1u);
-                    const u32 w0 = obase >> 5;
-                    if (own) atomicOr(&c_T[lane], own);
-#pragma unroll
-                    for (u32 w = 0; w < kCap / 32; ++w) {
-                        const u32 ow = c_O[w];
-                        if (ow && w0 + w < SNP_WAVE) atomicOr(&c_T[w0 + w], ow);
-                    }
-                }
-                lanes_sync_lds();
-                const u32 Tw = c_T[lane];
-                const u32 cnt = static_cast<u32>(__builtin_popcount(Tw));
-                const u32 cincl = wave_inclusive_scan(cnt);
-                ntok = read_lane(cincl, 63);
-                lanes_sync_lds();                                       // (every read of the scratch arrays is done: the list overwrites them)
-                // the list, transposed: entry t -> lane t % 64, slot t / 64 (32 bytes per lane), then into the lane's registers
-                u32 t = cincl - cnt, bits = Tw;
-                while (bits) {
-                    c_list[((t & 63u) << 4) + (t >> 6)] = static_cast<u16>(r0 + static_cast<u32>(__builtin_ctz(bits)));
-                    ++t;
-                    bits &= bits - 1u;
-                }
-                lanes_sync_lds();
-                {
-                    const u32x4 ea = *reinterpret_cast<const u32x4*>(c_scr + lane * 32u);
-                    const u32x4 eb = *reinterpret_cast<const u32x4*>(c_scr + lane * 32u + 16u);
-                    l0 = ea.x; l1 = ea.y; l2 = ea.z; l3 = ea.w;
-                    l4 = eb.x; l5 = eb.y; l6 = eb.z; l7 = eb.w;
-                }
-                lanes_sync_lds();
-                emitted = (SNP_D_ABLATE & 32) ? ntok : 0;               // (ablation: build the tag lists only)
-                DPROF_ADD(2, 1);                                        // super-windows
-                DPROF_ADD(9, __builtin_popcountll(active));             // lanes on the true chain
-                DPROF_TIME(11);                                         // chains, merge, tag list
-                if (emitted == ntok) continue;
-            }
-            // ---- one batch: the tags of the current slot from lane `lane0` on ----
-            const u32 avail = n - wbase;
-            const u32 lane0 = emitted & 63u;
-            const bool have = (lane >= lane0) & ((emitted & ~63u) + lane < ntok);
-            const u32 pos = have ? (l0 & 0xffffu) : 0u;
-            u64 q;
-            {
-                const u32* const pd = reinterpret_cast<const u32*>(c_in + (pos & ~3u));
-                const u32 d0 = pd[0], d1 = pd[1];
-                q = ((static_cast<u64>(d1) << 32) | d0) >> (8u * (pos & 3u));   // the tag byte + at least 4 more
-            }
-            const u32 c = static_cast<u32>(q) & 0xffu;
-            const u32 type = c & 3u;
-            const u32 hi6 = c >> 2;
-            const u32 b1234 = static_cast<u32>(q >> 8);
-            const bool is_lit = type == 0;
-            const bool long_lit = is_lit && hi6 >= 60;
-            const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
-            const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
-            const u32 len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);
-            const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
-            const u32 body = pos + 1u + extra;                          // a literal's bytes, from wbase
-            const u32 olen = have ? len : 0u;
-            const u32 incl = wave_inclusive_scan(olen);
-            const u32 ostart = op + incl - olen;
-            const bool lit_ok = ((len - 1u) < avail) & (body <= avail - len);   // the body lies inside the input (and, <= 64 bytes, inside the staged bytes)
-            const bool copy_ok = (off - 1u) < ostart;
-            const bool ok = have & ((is_lit & lit_ok) | (!is_lit & copy_ok)) & (incl + 16u <= expected - op);
-            const bool big = is_lit & (len > 64u);
-            const u64 okm = ballot64(ok & !big & (incl <= SNP_D_STAGE)) | lanes_below(lane0);
-            const u32 f = okm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~okm));   // the first lane that does not execute
-            if (f == lane0) {
-                const u32 f0 = read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), lane0);
-                SNP_D_FLUSH_CARRY();
-                if (f0 != 3u) {                                         // not ours: the serial loop decides, from this tag on
-                    ip = wbase + read_lane(pos, lane0);
-                    emitted = ntok = consumed = 0;                      // (ip is final)
-                    wbase = ip;
-                    break;
-                }
-                const u32 ll = read_lane(len, lane0);
-                if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wave_copy(dst + op, src + wbase + read_lane(body, lane0), ll, lane);
-                op += ll;
-                mark_g = op;
-                emitted += 1;
-                if ((emitted & 63u) == 0) {
-                    l0 = __builtin_amdgcn_alignbit(l1, l0, 16); l1 = __builtin_amdgcn_alignbit(l2, l1, 16); l2 = __builtin_amdgcn_alignbit(l3, l2, 16);
-                    l3 = __builtin_amdgcn_alignbit(l4, l3, 16); l4 = __builtin_amdgcn_alignbit(l5, l4, 16); l5 = __builtin_amdgcn_alignbit(l6, l5, 16);
-                    l6 = __builtin_amdgcn_alignbit(l7, l6, 16); l7 >>= 16;
-                }
-                continue;
-            }
-            const bool act = (lane >= lane0) & (lane < f);
-            const u32 span = read_lane(incl, f - 1);
-            const u32 s_lo = ostart - off;
-            const bool ready = act && (is_lit || (off >= len && s_lo + len <= mark_g));   // source in the input, or wholly in global memory
-            if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            u8* const my = c_stage + (ostart - mark_g);
-            // first pass, request: head and tail piece of every ready tag
-            u32x4 p0, p1;
-            const bool lit_q = is_lit & !long_lit & (len <= 4u);       // its bytes are in q
-            if (ready && !(SNP_D_ABLATE & 1)) {
-                if (is_lit) {
-                    if (lit_q) {
-                        p0 = u32x4{b1234, 0u, 0u, 0u};
-                    } else {
-                        p0 = ld128u(c_in + body);
-                        if (len > 16) p1 = ld128u(c_in + body + len - 16);
-                    }
-                } else {
-                    p0 = ld128u(dst + s_lo);
-                    if (len > 16) p1 = ld128u(dst + s_lo + len - 16);
-                }
-            }
-            u64 pend = ballot64(act && !ready);
-            DPROF_ADD(0, 1);
-            DPROF_ADD(1, f - lane0);
-            DPROF_ADD(5, __builtin_popcountll(pend));
-#if SNP_D_HOIST
-            // ... while they travel: which of the pending tags can the second pass take (source inside the stage, written by no pending tag)
-            bool blocked = off < len || s_lo < mark_g;                  // pattern copies and sources that reach below the stage: finished in order
-            const bool mine = (pend >> lane) & 1ull;
-            if ((SNP_D_ABLATE & 16) == 0 && (pend & (pend - 1))) {
-                {
-                    u32 z = 0;
-                    asm volatile("" : "+v"(z));                         // (see c_O above)
-                    c_busy[lane] = static_cast<u64>(z);
-                }
-                lanes_sync_lds();
-                if (mine) {
-                    const u32 r = ostart - mark_g, b0 = r & 63u;
-                    const u64 mk = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
-                    atomicOr(reinterpret_cast<unsigned long long*>(&c_busy[r >> 6]), static_cast<unsigned long long>(mk << b0));
-                    if (b0 && (mk >> (64u - b0)))
-                        atomicOr(reinterpret_cast<unsigned long long*>(&c_busy[(r >> 6) + 1]), static_cast<unsigned long long>(mk >> (64u - b0)));
-                }
-                lanes_sync_lds();
-                if (mine && !blocked) {
-                    const u32 lo = s_lo - mark_g, b0 = lo & 63u;
-                    const u64 mk = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
-                    const u64 w0 = c_busy[lo >> 6], w1 = c_busy[(lo >> 6) + 1];
-                    blocked = ((w0 & (mk << b0)) | (b0 ? (w1 & (mk >> (64u - b0))) : 0ull)) != 0ull;
-                }
-            }
-            // first pass, store
-            if (ready && !(SNP_D_ABLATE & 1)) {
-                if (len >= 16) {
-                    st128u(my, p0);
-                    if (len > 16) st128u(my + len - 16, p1);
-                } else {
-                    const bool c8 = (len & 8u) != 0, c4 = (len & 4u) != 0, c2 = (len & 2u) != 0;
-                    const u32 x0 = c8 ? p0.z : p0.x;
-                    const u32 x1 = c8 ? p0.w : p0.y;
-                    const u32 y0 = c4 ? x1 : x0;
-                    const u32 z0 = c2 ? y0 >> 16 : y0;
-                    const u32 o4 = len & 8u, o2 = len & 12u, o1 = len & 14u;
-                    if (c8) reinterpret_cast<snp_u64_unaligned*>(my)->v = p0.x | (static_cast<u64>(p0.y) << 32);
-                    if (c4) st32u(my + o4, x0);
-                    if (c2) reinterpret_cast<snp_u16_unaligned*>(my + o2)->v = static_cast<u16>(y0);
-                    if (len & 1u) my[o1] = static_cast<u8>(z0);
-                }
-                if (len > 32) {                                         // the middle pieces of a long tag: a second round trip (10 % of the copies)
-                    u32x4 p2, p3;
-                    if (is_lit) { p2 = ld128u(c_in + body + 16); p3 = ld128u(c_in + body + min(32u, len - 16u)); }
-                    else { p2 = ld128u(dst + s_lo + 16); p3 = ld128u(dst + s_lo + min(32u, len - 16u)); }
-                    asm volatile("" ::"v"(p2), "v"(p3));
-                    st128u(my + 16, p2);
-                    if (len > 48) st128u(my + 32, p3);
-                }
-            }
-#else
-            // first pass, store
-            if (ready && !(SNP_D_ABLATE & 1)) {
-                if (len >= 16) {
-                    st128u(my, p0);
-                    if (len > 16) st128u(my + len - 16, p1);
-                } else {
-                    const bool c8 = (len & 8u) != 0, c4 = (len & 4u) != 0, c2 = (len & 2u) != 0;
-                    const u32 x0 = c8 ? p0.z : p0.x;
-                    const u32 x1 = c8 ? p0.w : p0.y;
-                    const u32 y0 = c4 ? x1 : x0;
-                    const u32 z0 = c2 ? y0 >> 16 : y0;
-                    const u32 o4 = len & 8u, o2 = len & 12u, o1 = len & 14u;
-                    if (c8) reinterpret_cast<snp_u64_unaligned*>(my)->v = p0.x | (static_cast<u64>(p0.y) << 32);
-                    if (c4) st32u(my + o4, x0);
-                    if (c2) reinterpret_cast<snp_u16_unaligned*>(my + o2)->v = static_cast<u16>(y0);
-                    if (len & 1u) my[o1] = static_cast<u8>(z0);
-                }
-                if (len > 32) {                                         // the middle pieces of a long tag: a second round trip (10 % of the copies)
-                    u32x4 p2, p3;
-                    if (is_lit) { p2 = ld128u(c_in + body + 16); p3 = ld128u(c_in + body + min(32u, len - 16u)); }
-                    else { p2 = ld128u(dst + s_lo + 16); p3 = ld128u(dst + s_lo + min(32u, len - 16u)); }
-                    asm volatile("" ::"v"(p2), "v"(p3));
-                    st128u(my + 16, p2);
-                    if (len > 48) st128u(my + 32, p3);
-                }
-            }
-            // ... while they travel: which of the pending tags can the second pass take (source inside the stage, written by no pending tag)
-            bool blocked = off < len || s_lo < mark_g;                  // pattern copies and sources that reach below the stage: finished in order
-            const bool mine = (pend >> lane) & 1ull;
-            if ((SNP_D_ABLATE & 16) == 0 && (pend & (pend - 1))) {
-                {
-                    u32 z = 0;
-                    asm volatile("" : "+v"(z));                         // (see c_O above)
-                    c_busy[lane] = static_cast<u64>(z);
-                }
-                lanes_sync_lds();
-                if (mine) {
-                    const u32 r = ostart - mark_g, b0 = r & 63u;
-                    const u64 mk = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
-                    atomicOr(reinterpret_cast<unsigned long long*>(&c_busy[r >> 6]), static_cast<unsigned long long>(mk << b0));
-                    if (b0 && (mk >> (64u - b0)))
-                        atomicOr(reinterpret_cast<unsigned long long*>(&c_busy[(r >> 6) + 1]), static_cast<unsigned long long>(mk >> (64u - b0)));
-                }
-                lanes_sync_lds();
-                if (mine && !blocked) {
-                    const u32 lo = s_lo - mark_g, b0 = lo & 63u;
-                    const u64 mk = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
-                    const u64 w0 = c_busy[lo >> 6], w1 = c_busy[(lo >> 6) + 1];
-                    blocked = ((w0 & (mk << b0)) | (b0 ? (w1 & (mk >> (64u - b0))) : 0ull)) != 0ull;
-                }
-            }
-#endif
-            DPROF_TIME(12);                                             // tag bytes, decode, prefix sum, first pass
-            if (pend) {
-                const bool ready2 = SNP_D_PASS2 && mine && !blocked;
-                lanes_sync_lds();
-                if (ready2) lane_copy2(my, c_stage + (s_lo - mark_g), len);
-                pend &= ~ballot64(ready2);
-                DPROF_ADD(4, __builtin_popcountll(pend));
-                DPROF_TIME(13);
-                // the rest in order, whole wave per tag, a byte per lane
-                if (SNP_D_ABLATE & 2) pend = 0;
-                while (pend) {
-                    const u32 fl = static_cast<u32>(__builtin_ctzll(pend));
-                    pend &= pend - 1;
-                    const u32 f_o = read_lane(ostart, fl), f_off = read_lane(off, fl), f_len = read_lane(len, fl);
-                    u32 sidx = lane;
-                    if (f_off < f_len) {
-#pragma unroll
-                        for (int sh = 5; sh >= 0; --sh) {
-                            const u32 tt = f_off << sh;
-                            sidx = min(sidx, sidx - tt);
-                        }
-                    }
-                    const u32 rel = f_o - mark_g;
-                    if (rel >= f_off) {                                 // the whole source lies in the stage
-                        if (lane < f_len) c_stage[rel + lane] = c_stage[rel - f_off + sidx];
-                    } else {                                            // it starts below it: those bytes are in global memory
-                        const u32 spos = f_o - f_off + sidx;
-                        u32 byte = 0;
-                        if (lane < f_len) {
-                            if (spos < mark_g) byte = dst[spos];
-                            else byte = c_stage[spos - mark_g];
-                        }
-                        if (lane < f_len) c_stage[rel + lane] = static_cast<u8>(byte);
-                    }
-                }
-            }
-            // write-out: whole 16-byte chunks of the ADDRESS space, the rest is carried
-            lanes_sync_lds();
-            op += span;
-            if (!(SNP_D_ABLATE & 4)) {
-                const u32 tot = op - mark_g;                            // stage[0 .. tot) = output [mark_g, op)
-                u8* const g = dst + mark_g;
-                const u32 head = (0u - (a0 + mark_g)) & 15u;            // to the next 16-byte boundary: 0 except after a start that was not aligned
-                u32 done = 0;
-                if (head && tot >= head) {
-                    if (lane < head) g[lane] = c_stage[lane];
-                    done = head;
-                }
-                if (!head || done) {
-                    const u32 full = SNP_D_ALIGNED_OUT ? ((tot - done) & ~15u) : (tot - done);
-                    const u32 tail = full & ~15u;
-                    for (u32 i = lane * 16; i < tail; i += SNP_WAVE * 16)
-                        *reinterpret_cast<snp_u128_unaligned*>(g + done + i) = *reinterpret_cast<const snp_u128_unaligned*>(c_stage + done + i);
-                    if (!SNP_D_ALIGNED_OUT) {
-                        if (tail + lane < full) g[done + tail + lane] = c_stage[done + tail + lane];
-                    }
-                    done += full;
-                }
-                if (done) {
-                    if (done < tot && lane == 0) {
-                        const u32x4 rest = ld128u(c_stage + done);      // (< 16 bytes are live; the excess is overwritten or never read)
-                        st128u(c_stage, rest);
-                    }
-                    mark_g += done;
-                }
-            } else {
-                mark_g = op;
-            }
-            lanes_sync_lds();
-            emitted += f - lane0;
-            if (f == 64u) {                                             // the slot is used up: the next entry moves into the low half of l0
-                l0 = __builtin_amdgcn_alignbit(l1, l0, 16); l1 = __builtin_amdgcn_alignbit(l2, l1, 16); l2 = __builtin_amdgcn_alignbit(l3, l2, 16);
-                l3 = __builtin_amdgcn_alignbit(l4, l3, 16); l4 = __builtin_amdgcn_alignbit(l5, l4, 16); l5 = __builtin_amdgcn_alignbit(l6, l5, 16);
-                l6 = __builtin_amdgcn_alignbit(l7, l6, 16); l7 >>= 16;
-            }
-            DPROF_TIME(14);
-        }
-        SNP_D_FLUSH_CARRY();
-#undef SNP_D_FLUSH_CARRY
-        DPROF_FLUSH;
-        w.wv = 0x80000000u;
-    }
-#else
     if (FRONT == 3) {
         constexpr u32 kR = 32;                                          // input bytes per lane region
         constexpr u32 kW = SNP_WAVE * kR;                               // the super-window
@@ -1338,7 +849,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     // the bytes it rewrites are the same bytes), pieces beyond it are not needed
                     const u32 oa = lane * 16u, ob = oa + 1024u;
                     const u32 la = min(oa, avail - 16u), lb = min(ob, avail - 16u);
-                    const u32x4 va = ld128u_in(wsrc + la), vb = ld128u_in(wsrc + lb);
+                    const u32x4 va = ld128u(wsrc + la), vb = ld128u(wsrc + lb);
                     st128u(c_in + la, va);
                     st128u(c_in + lb, vb);
                 }
@@ -1466,7 +977,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             const u32 t = emitted + lane;
             const bool have = t < ntok;
             const u32 pos = have ? c_pos[t] : 0u;
-            const u64 q = pf_at == emitted ? q_pf : ld64u_in(src + wbase + pos);   // pos < L (idle lanes re-read position 0)
+            const u64 q = pf_at == emitted ? q_pf : ld64u(src + wbase + pos);   // pos < L (idle lanes re-read position 0)
             const u32 c = static_cast<u32>(q) & 0xffu;
             const u32 type = c & 3u;
             const u32 hi6 = c >> 2;
@@ -1506,22 +1017,20 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             const u32 mark = op;                                        // all output below it is complete
             const u32 span = read_lane(incl, ne - 1);
             const bool ready = act && (is_lit || (off >= len && ostart - off + len <= mark));
+            DPROF_TIME(12);                                             // tag bytes (+ whatever the wave still waits for at the batch top), decode, prefix sum, checks
             if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pf_at = SNP_D_PF ? emitted + ne : ~0u;                      // the next batch's tag bytes travel with this batch's copies
-            if (pf_at < ntok) q_pf = ld64u_in(src + wbase + (pf_at + lane < ntok ? c_pos[pf_at + lane] : 0u));
+            if (pf_at < ntok) q_pf = ld64u(src + wbase + (pf_at + lane < ntok ? c_pos[pf_at + lane] : 0u));
             u8* const my = c_stage + (ostart - mark);
             const u32 s_lo = ostart - off;
-#if SNP_D_QLIT
-            if (ready && !(SNP_D_ABLATE & 1)) lane_copy2<true>(my, is_lit ? src + wbase + body : dst + s_lo, len, is_lit & !long_lit & (len <= 7u), q >> 8);
-#else
-            // (timing-only ablation 64: every copy source pulled to within 1 KiB below the batch -- what would far back-references cost nothing?)
+            // (timing-only ablation 64: every copy source pulled to within 1 KiB below the batch -- what if far back-references cost nothing?
+            //  10.9 vs 11.2 ms, profiles/r03b_decode_far_source_ablation.jsonl: they nearly do already)
             if (ready && !(SNP_D_ABLATE & 1)) lane_copy2(my, is_lit ? src + wbase + body : dst + ((SNP_D_ABLATE & 64) ? max(s_lo, max(mark, 1024u) - 1024u) : s_lo), len);
-#endif
             u64 pend = ballot64(act && !ready);
             DPROF_ADD(0, 1);
             DPROF_ADD(1, ne);
             DPROF_ADD(5, __builtin_popcountll(pend));
-            DPROF_TIME(12);                                             // tag bytes, decode, prefix sum, first pass
+            DPROF_TIME(13);                                             // first pass: source loads, stage stores
             if (pend) {
                 // second lane-parallel pass: sources inside the batch that no pending tag still has to write
                 bool blocked = off < len || s_lo < mark;                // pattern copies and sources straddling `mark`: finished in order
@@ -1549,7 +1058,6 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 if (ready2) lane_copy2(my, c_stage + (s_lo - mark), len);
                 pend &= ~ballot64(ready2);
                 DPROF_ADD(4, __builtin_popcountll(pend));
-                DPROF_TIME(13);
                 // The rest in order, whole wave per tag, a byte per lane.  (This loop runs ~5 times per batch and is mostly scalar
                 // work -- the busiest unit of this kernel -- so the common case, a source inside the stage, is kept to one
                 // LDS read and one LDS write under one exec mask; LDS operations of a wave execute in order.)
@@ -1580,6 +1088,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     }
                 }
             }
+            DPROF_TIME(14);                                             // second pass + in-order finish
             // the whole run, coalesced
             lanes_sync_lds();
             u8* const g = dst + mark;
@@ -1592,12 +1101,11 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             lanes_sync_lds();
             op += span;
             emitted += ne;
-            DPROF_TIME(14);
+            DPROF_TIME(15);                                             // write-out, until the stores are acknowledged
         }
         DPROF_FLUSH;
         w.wv = 0x80000000u;
     }
-#endif
 
     u32 fenced = 0;   // output bytes below this are known to have left the wave's store queue (FENCED only)
 

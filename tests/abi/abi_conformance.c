@@ -11,6 +11,7 @@
  * TEST INFRASTRUCTURE.
  */
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,8 +49,37 @@ typedef const char* (*fn_version)(void);
 typedef int64_t (*fn_len)(int64_t);
 typedef int32_t (*fn_get_ulen)(const uint8_t*, size_t, uint32_t*, uint32_t*);
 typedef int32_t (*fn_buf)(void*, const uint8_t*, size_t, uint8_t*, size_t, size_t*);
+typedef int32_t (*fn_segs)(void*, const uint8_t* const*, const size_t*, uint32_t, uint8_t*, size_t, size_t*);
 typedef int32_t (*fn_crc)(void*, const uint8_t*, size_t, int32_t, uint32_t*);
 typedef int32_t (*fn_frame_len)(const uint8_t*, size_t, uint64_t*);
+
+/* ---- several callers at once: Snappy.* is re-entrant (Snappy.cs:64,174,225 news up a compressor per call), so the shim keeps one
+ * context per calling thread (GpuContext, [ThreadStatic]) -- and one per DEVICE when the host has several (the multi-GPU path below
+ * Python: a C# service on an 8-GPU node opens eight contexts in one process).  Each thread: its own context on device
+ * `device`, round trips of its own slice of the data, results compared with what the main thread's context produced. */
+typedef struct {
+    fn_ctx_create ctx_create; fn_ctx_destroy ctx_destroy; fn_buf try_compress, try_decompress; fn_len max_len;
+    int device; const uint8_t* data; size_t n; const uint8_t* want; size_t want_len; int rounds; int fails; int created;
+} worker_arg;
+
+static void* worker(void* p)
+{
+    worker_arg* a = (worker_arg*)p;
+    void* ctx = NULL;
+    if (a->ctx_create(a->device, SNP_HASH_CRC32C, NULL, &ctx) != SNP_OK || !ctx) { a->created = 0; return NULL; }
+    a->created = 1;
+    const size_t cap = (size_t)a->max_len((int64_t)a->n);
+    uint8_t* comp = malloc(cap);
+    uint8_t* back = malloc(a->n + 16);
+    for (int r = 0; r < a->rounds; ++r) {
+        size_t w = 0, w2 = 0;
+        if (a->try_compress(ctx, a->data, a->n, comp, cap, &w) != SNP_OK || w != a->want_len || memcmp(comp, a->want, w) != 0) ++a->fails;
+        if (a->try_decompress(ctx, comp, w, back, a->n, &w2) != SNP_OK || w2 != a->n || memcmp(back, a->data, a->n) != 0) ++a->fails;
+    }
+    a->ctx_destroy(ctx);
+    free(comp); free(back);
+    return NULL;
+}
 
 static void* must(void* lib, const char* name)
 {
@@ -69,7 +99,7 @@ int main(int argc, char** argv)
     static const char* all[] = {
         "snp_ctx_create", "snp_ctx_destroy", "snp_ctx_set_stream", "snp_ctx_last_error", "snp_ctx_synchronize", "snp_ctx_counter",
         "snp_ctx_set_option", "snp_ctx_get_option", "snp_status_string", "snp_version", "snp_max_compressed_length", "snp_max_fragment_compressed_length",
-        "snp_get_uncompressed_length", "snp_try_compress", "snp_try_decompress", "snp_crc32c", "snp_frame_max_encoded_length",
+        "snp_get_uncompressed_length", "snp_try_compress", "snp_try_decompress", "snp_try_compress_segments", "snp_try_decompress_segments", "snp_crc32c", "snp_frame_max_encoded_length",
         "snp_frame_encode", "snp_frame_decoded_length", "snp_frame_decode", "snp_compress_batch", "snp_decompress_batch",
         "snp_crc32c_batch", "snp_concat_batch", "snp_frame_encode_workspace", "snp_frame_encode_device",
         "snp_frame_decode_chunks_device", "snp_frame_decode_workspace", "snp_frame_decode_device"};
@@ -90,6 +120,8 @@ int main(int argc, char** argv)
     fn_get_ulen get_ulen = (fn_get_ulen)must(lib, "snp_get_uncompressed_length");
     fn_buf try_compress = (fn_buf)must(lib, "snp_try_compress");
     fn_buf try_decompress = (fn_buf)must(lib, "snp_try_decompress");
+    fn_segs compress_segments = (fn_segs)must(lib, "snp_try_compress_segments");
+    fn_segs decompress_segments = (fn_segs)must(lib, "snp_try_decompress_segments");
     fn_buf frame_encode = (fn_buf)must(lib, "snp_frame_encode");
     fn_buf frame_decode = (fn_buf)must(lib, "snp_frame_decode");
     fn_crc crc32c = (fn_crc)must(lib, "snp_crc32c");
@@ -182,6 +214,25 @@ int main(int argc, char** argv)
         uint8_t junk[8] = {0x08, 0x0c, 'a', 'b', 'c', 'd', 0x05, 0x09};  /* declared 8: literal "abcd" then a copy with offset 9 > 4 */
         EXPECT(try_decompress(ctx, junk, sizeof junk, back, 8, &w2) == SNP_ERR_BAD_OFFSET);
     }
+    /* Snappy.Compress / DecompressToMemory(ReadOnlySequence): the same input as three (two) pinned segments -> the same bytes */
+    {
+        const uint8_t* seg[3] = {data, data + 70001, data + 70001 + 3};
+        const size_t seg_len[3] = {70001, 3, n - 70004};
+        uint8_t* comp2 = malloc(cap);
+        size_t ws = 0, wd = 0;
+        EXPECT(try_compress(ctx, data, n, comp, cap, &w) == SNP_OK);
+        EXPECT(compress_segments(ctx, seg, seg_len, 3, comp2, cap, &ws) == SNP_OK && ws == w && memcmp(comp2, comp, w) == 0);
+        EXPECT(compress_segments(ctx, seg, seg_len, 3, comp2, 10, &ws) == SNP_ERR_OUTPUT_TOO_SMALL && ws == 0);
+        EXPECT(compress_segments(ctx, seg, seg_len, 0, comp2, cap, &ws) == SNP_OK && ws == 1 && comp2[0] == 0);   /* the empty sequence */
+        const uint8_t* cseg[2] = {comp, comp + 2};                       /* the varint preamble itself split over two segments */
+        const size_t cseg_len[2] = {2, w - 2};
+        EXPECT(decompress_segments(ctx, cseg, cseg_len, 2, back, n, &wd) == SNP_OK && wd == n && memcmp(back, data, n) == 0);
+        EXPECT(decompress_segments(ctx, cseg, cseg_len, 2, back, n - 1, &wd) == SNP_ERR_OUTPUT_TOO_SMALL && wd == 0);
+        const size_t cut_len[2] = {2, w / 2};
+        EXPECT(decompress_segments(ctx, cseg, cut_len, 2, back, n, &wd) == SNP_ERR_INCOMPLETE);
+        EXPECT(compress_segments(ctx, NULL, NULL, 2, comp2, cap, &ws) == SNP_ERR_BAD_ARG);
+        free(comp2);
+    }
     /* one small buffer (a single fragment, the Snappy.CompressToArray("hello") case) */
     EXPECT(try_compress(ctx, (const uint8_t*)"hello hello hello hello", 23, comp, cap, &w) == SNP_OK);
     EXPECT(try_decompress(ctx, comp, w, back, 23, &w2) == SNP_OK && w2 == 23 && memcmp(back, "hello hello hello hello", 23) == 0);
@@ -205,6 +256,31 @@ int main(int argc, char** argv)
     framed[10] = 0x00;
     uint32_t crc = 0;
     EXPECT(crc32c(ctx, (const uint8_t*)"123456789", 9, 0, &crc) == SNP_OK && crc == 0xE3069283u);   /* Crc32CAlgorithmTests.cs */
+
+    /* ---- several contexts in one process: four threads, contexts spread over every device the host has ------------- */
+    {
+        int ndev = 1;
+        for (int d = 1; d < 16; ++d) {                                   /* how many devices?  (no HIP here: ask snp_ctx_create) */
+            void* probe = NULL;
+            if (ctx_create(d, SNP_HASH_CRC32C, NULL, &probe) != SNP_OK) break;
+            ctx_destroy(probe);
+            ndev = d + 1;
+        }
+        size_t wl = 0;
+        EXPECT(try_compress(ctx, data, n, comp, cap, &wl) == SNP_OK);
+        enum { kThreads = 4 };
+        pthread_t th[kThreads];
+        worker_arg args[kThreads];
+        for (int t = 0; t < kThreads; ++t) {
+            args[t] = (worker_arg){ctx_create, ctx_destroy, try_compress, try_decompress, max_len, t % ndev, data, n, comp, wl, 6, 0, 0};
+            EXPECT(pthread_create(&th[t], NULL, worker, &args[t]) == 0);
+        }
+        for (int t = 0; t < kThreads; ++t) {
+            pthread_join(th[t], NULL);
+            EXPECT(args[t].created == 1 && args[t].fails == 0);
+        }
+        printf("%d threads x 6 round trips on %d device(s): %s\n", kThreads, ndev, g_fail ? "FAIL" : "ok");
+    }
     ctx_destroy(ctx);
     free(comp); free(back); free(exact); free(framed);
     printf("%s (device part)\n", g_fail ? "NOT CONFORMING" : "conforming");

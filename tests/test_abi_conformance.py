@@ -18,7 +18,7 @@ LIB = os.path.join(ROOT, "snappier_amd", "libsnappier_hip.so")
 
 def build():
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(ROOT, "include", "snappier_hip.h"))):
-        subprocess.run(["gcc", "-O1", "-std=c11", "-Wall", "-Wextra", "-o", EXE, SRC, "-ldl"], check=True)
+        subprocess.run(["gcc", "-O1", "-std=c11", "-Wall", "-Wextra", "-o", EXE, SRC, "-ldl", "-lpthread"], check=True)
     return EXE
 
 

@@ -21,6 +21,21 @@ def test_library_built_and_exports_every_declared_symbol():
         assert hasattr(L, s), s
 
 
+def test_every_exported_snp_symbol_is_declared_in_a_header():
+    """Nothing is exported behind the headers' back: every snp_* function the .so exports is declared either in the product
+    header or in include/snappier_hip_debug.h (test hooks), apart from the launchers the translation units call among themselves."""
+    import re
+    import subprocess
+    from snappier_amd import _native as N
+    out = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {m.group(1) for m in re.finditer(r" T (snp_[a-z0-9_]+)$", out, flags=re.M)}
+    internal = {e for e in exported if e.startswith(("snp_launch_", "snp_probe_", "snp_compress_lanes_workspace", "snp_frame_scan_workspace", "snp_tag_index_entries"))}
+    dbg = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "snappier_hip_debug.h")).read(), flags=re.S)
+    debug_declared = set(re.findall(r"\b(snp_debug_[a-z0-9_]+)\s*\(", dbg))
+    assert debug_declared == {e for e in exported if e.startswith("snp_debug_")}, (debug_declared, exported)
+    assert exported - internal - debug_declared == set(N.declared_symbols()), sorted(exported - internal - debug_declared - set(N.declared_symbols()))
+
+
 def test_product_package_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "snappier_amd")
     for dirpath, _d, files in os.walk(pkg):

@@ -172,6 +172,20 @@ def test_find_match_length_kats_on_the_device(expected, s1, s2, length):   # Sna
     assert rc == 0 and int(out.item()) == expected == O.find_match_length(s1.encode(), s2.encode(), length)
 
 
+@pytest.mark.parametrize("expected,s1,s2,length", kats.FIND_MATCH_LENGTH)
+def test_find_match_length_kats_on_the_lane_kernels_function(expected, s1, s2, length):   # SnappyCompressorTests.cs:10-96
+    """The same KATs through the HEADLINE kernel's form of FindMatchLength (compress_lanes.hip, lane_find_match_length; hook declared
+    in include/snappier_hip_debug.h): s1 at 0, s2 at len(s1), fragment end = the KAT's s2Limit."""
+    import ctypes as C
+    L = S.lib()
+    buf = to_dev(np.frombuffer((s1 + s2).encode() + bytes(16), dtype=np.uint8))
+    out = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = L.snp_debug_lane_match_length(C.c_void_p(buf.data_ptr()), C.c_uint32(len(s1) + length), C.c_uint32(0), C.c_uint32(len(s1)),
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and int(out.item()) == expected == O.find_match_length(s1.encode(), s2.encode(), length)
+
+
 # ------------------------------------------------------------------ compress (bit-exact against the oracle)
 
 @pytest.mark.parametrize("variant", VARIANTS)
