@@ -77,14 +77,19 @@ __device__ __forceinline__ u32 xstep8(u32 v)
 
 constexpr u32 kCrcWaves = 4;   // byte ranges per workgroup (they share the LDS table)
 
+// TABLE_FREE = true: the form BASELINE.json's north star names -- no table anywhere, X8192 applied bit by bit (32 x sbfe / and / xor
+// per dword: VALU-bound, 1.7 TB/s; SNP_OPT_CRC_TABLE_FREE selects it).  The default keeps the four 256-entry tables in LDS (4.5-5.3 TB/s).
+template <bool TABLE_FREE>
 __global__ __launch_bounds__(SNP_WAVE * kCrcWaves) void k_crc32c(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                                 const u32* __restrict__ in_len, u32 nblocks, int masked,
                                                                 u32* __restrict__ out_crc, const u32* __restrict__ expect,
                                                                 i32* __restrict__ status)
 {
-    __shared__ u32 T[4][256];
-    for (u32 e = threadIdx.x; e < 1024; e += SNP_WAVE * kCrcWaves) T[e >> 8][e & 255u] = g_crc_lut.t[e >> 8][e & 255u];
-    __syncthreads();
+    __shared__ u32 T[TABLE_FREE ? 1 : 4][256];
+    if (!TABLE_FREE) {
+        for (u32 e = threadIdx.x; e < 1024; e += SNP_WAVE * kCrcWaves) T[e >> 8][e & 255u] = g_crc_lut.t[e >> 8][e & 255u];
+        __syncthreads();
+    }
     const u32 b = blockIdx.x * kCrcWaves + (threadIdx.x >> 6);
     if (b >= nblocks) return;
     const u32 lane = lane_id();
@@ -129,7 +134,8 @@ __global__ __launch_bounds__(SNP_WAVE * kCrcWaves) void k_crc32c(const u8* __res
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const u32 a = acc[d];
-                acc[d] = T[0][a & 255u] ^ T[1][(a >> 8) & 255u] ^ T[2][(a >> 16) & 255u] ^ T[3][a >> 24] ^ cur[d];
+                if constexpr (TABLE_FREE) acc[d] = xmul<8192>(a) ^ cur[d];
+                else acc[d] = T[0][a & 255u] ^ T[1][(a >> 8) & 255u] ^ T[2][(a >> 16) & 255u] ^ T[3][a >> 24] ^ cur[d];
             }
 #pragma unroll
             for (int d = 0; d < 4; ++d) cur[d] = nxt[d];
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(SNP_WAVE * kCrcWaves) void k_crc32c(const u8* __res
         v ^= __shfl_xor(v, 32, 64);
         crc = xmul<32>(v) ^ 0xffffffffu;                                // Crc32CAlgorithm.cs:48,153 final xor
     }
-    if (masked) crc = crc32c_mask(crc);                                 // ApplyMask  :156-158
+    if (masked & 1) crc = crc32c_mask(crc);                             // ApplyMask  :156-158
     if (lane == 0) {
         if (out_crc) out_crc[b] = crc;
         // framing verify: "Chunk CRC mismatch."  SnappyStreamDecompressor.cs:127-131,170-174
@@ -164,7 +170,12 @@ extern "C" hipError_t snp_launch_crc32c(const u8* in, const u64* in_off, const u
                                         u32* out_crc, const u32* expect, i32* status, hipStream_t stream)
 {
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_crc32c, dim3((nblocks + kCrcWaves - 1) / kCrcWaves), dim3(SNP_WAVE * kCrcWaves), 0, stream, in, in_off, in_len, nblocks, masked,
-                       out_crc, expect, status);
+    // masked: bit 0 = apply the framing mask, bit 1 = the table-free kernel
+    if (masked & 2)
+        hipLaunchKernelGGL(k_crc32c<true>, dim3((nblocks + kCrcWaves - 1) / kCrcWaves), dim3(SNP_WAVE * kCrcWaves), 0, stream, in, in_off, in_len, nblocks,
+                           masked, out_crc, expect, status);
+    else
+        hipLaunchKernelGGL(k_crc32c<false>, dim3((nblocks + kCrcWaves - 1) / kCrcWaves), dim3(SNP_WAVE * kCrcWaves), 0, stream, in, in_off, in_len, nblocks,
+                           masked, out_crc, expect, status);
     return hipGetLastError();
 }

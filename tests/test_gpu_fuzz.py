@@ -339,3 +339,26 @@ def test_context_options_pin_layouts_without_changing_results():
         assert np.array_equal(back.cpu().numpy()[: data.size], data), layout
     ctx.set_option(N.OPT_COMPRESS_LAYOUT, 0)
     ctx.set_option(N.OPT_DECODE_LAYOUT, 0)
+
+
+def test_crc32c_table_free_kernel_equals_the_table_kernel_and_the_oracle():
+    """SNP_OPT_CRC_TABLE_FREE (the kernel BASELINE.json's north star names: no table, the GF(2) shift map bit by bit) against the default
+    LDS-table kernel and the oracle (Crc32CAlgorithm.cs:41-158): ragged lengths 0 .. 70 000, masked and unmasked, and through the
+    framing format (snp_frame_encode computes every chunk's CRC with the selected kernel, snp_frame_decode verifies with it)."""
+    N = S._native
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    rng = np.random.default_rng(11)
+    lens = [0, 1, 2, 3, 4, 5, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 65535, 65536, 70000] + [int(x) for x in rng.integers(0, 70000, 200)]
+    blocks = [rng.integers(0, 256, n, dtype=np.uint8) for n in lens]
+    data, off, ln = batch_of(blocks)
+    want = {m: np.array([O.crc32c(b.tobytes(), masked=m) for b in blocks], dtype=np.uint32) for m in (False, True)}
+    for table_free in (1, 0, 1):
+        cd.ctx.set_option(N.OPT_CRC_TABLE_FREE, table_free)
+        assert cd.ctx.get_option(N.OPT_CRC_TABLE_FREE) == table_free
+        for m in (False, True):
+            got = cd.crc32c(dev(data), dev(off), dev(ln), masked=m).cpu().numpy().astype(np.uint32)
+            assert np.array_equal(got, want[m]), (table_free, m, np.nonzero(got != want[m])[0][:5])
+        payload = read_testdata("html") * 2
+        framed = S.frame_encode(payload, cd.ctx)
+        assert framed == O.frame_encode(payload) and S.frame_decode(framed, cd.ctx) == payload
+    cd.ctx.set_option(N.OPT_CRC_TABLE_FREE, 0)
