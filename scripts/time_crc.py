@@ -12,6 +12,8 @@ html = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "te
 cd = SB.BlockCodec(0, S.HASH_CRC32C)
 raw = SD.html_like_blocks(html, 0, nb, "cuda")
 in_off, in_len = cd.uniform_layout(nb)
+table_free = int(os.environ.get("TABLE_FREE", "0"))      # 1 = the table-free kernel (SNP_OPT_CRC_TABLE_FREE)
+cd.ctx.set_option(S._native.OPT_CRC_TABLE_FREE, table_free)
 ms = []
 for i in range(4):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,5 +23,5 @@ for i in range(4):
     torch.cuda.synchronize()
     ms.append(e0.elapsed_time(e1))
 t = min(ms[1:])
-print(json.dumps({"kernel": "k_crc32c", "chunks": nb, "ms": [round(m, 3) for m in ms], "GBps": round(nb * 65536 / t / 1e6, 1),
+print(json.dumps({"kernel": "k_crc32c<table_free>" if table_free else "k_crc32c", "chunks": nb, "ms": [round(m, 3) for m in ms], "GBps": round(nb * 65536 / t / 1e6, 1),
                   "frac_of_8TBps": round(nb * 65536 / t / 1e6 / 8000, 4), "checksum_of_checksums": int(crc.to(torch.int64).sum().item())}))

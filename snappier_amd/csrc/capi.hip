@@ -207,6 +207,7 @@ struct snp_ctx {
         if (chint && chint_ev && chint_pending && hipEventQuery(chint_ev) == hipSuccess) {
             chint_pending = false;
             chint_small = chint[0] != 0 && chint[0] <= 512;
+            chint_mid = chint[0] != 0 && chint[0] <= 4096;
         } else {
             (void)hipGetLastError();
         }
@@ -218,7 +219,9 @@ struct snp_ctx {
         // former: profiles/r02w_small_block_compress.jsonl).  What the fragments are like is known only on the device, so the longest
         // fragment of the previous launch comes back with an asynchronous 4-byte copy (read above, only once it has landed) and this
         // batch is assumed to be alike; results do not depend on it.
-        const int lanes_per_wave = chint_small ? 32 : 0;
+        // (bit 8: two speculative probes per trip whatever the batch size -- fragments of at most 4 KiB are latency-bound, not request-bound:
+        //  1 KiB blocks 45.6 GB/s with one exchange probe, 48.3-49.0 with two probes, profiles/r03p_small_compress_sweep.jsonl)
+        const int lanes_per_wave = (chint_small ? 32 : 0) | (chint_mid ? 256 : 0);
         for (u32 first = 0; first < nblocks; first += kSlice) {
             const u32 cnt = nblocks - first < kSlice ? nblocks - first : kSlice;
             if (!check(snp_launch_compress_lanes(d_in, in_off + first, in_len + first, cnt, d_out, out_off + first,
@@ -237,7 +240,7 @@ struct snp_ctx {
     }
     u32* chint = nullptr;                                // pinned: the longest fragment of the previous lane-compressor launch
     hipEvent_t chint_ev = nullptr;
-    bool chint_pending = false, chint_small = false;
+    bool chint_pending = false, chint_small = false, chint_mid = false;
     bool chint_ready()
     {
         if (!chint && hipHostMalloc(reinterpret_cast<void**>(&chint), 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); chint = nullptr; return false; }

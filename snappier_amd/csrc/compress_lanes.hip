@@ -638,6 +638,8 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // Fragments per wavefront: 64 when there are enough fragments to fill the chip that way; fewer (partially filled
     // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
     const char* env = getenv("SNAPPIER_HIP_LANES_PER_WAVE");
+    const bool two_probes = (lanes_per_wave & 256) != 0;               // the context's hint: small fragments (capi.hip)
+    lanes_per_wave &= 255;
     u32 per = env ? static_cast<u32>(atoi(env)) : lanes_per_wave ? static_cast<u32>(lanes_per_wave) : (nblocks >= 131072 ? 64u : nblocks >= 8192 ? 32u : 16u);   // measured: scripts/sweep_layouts.py
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
     const u32 grid = (nblocks + per - 1) / per;
@@ -654,7 +656,9 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
     // one probe is 1.5 % faster at 163 840)
-    const u32 slots = se ? static_cast<u32>(atoi(se)) : (nblocks >= 131072 ? kDefaultSlots : 2u);
+    // (... and for batches of SMALL fragments at any size -- bit 8 of lanes_per_wave is the context's hint for them: they are latency-bound, not
+    // request-bound: 256-byte blocks 40.7 GB/s with one exchange probe per trip, 46.5 with two speculative probes, profiles/r03p_small_compress_sweep.jsonl)
+    const u32 slots = se ? static_cast<u32>(atoi(se)) : ((nblocks >= 131072 && !two_probes) ? kDefaultSlots : 2u);
 #define SNP_LAUNCH_CL(V, S)                                                                                          \
     hipLaunchKernelGGL((k_compress_lanes<V, S>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
                        out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind, max_len)
