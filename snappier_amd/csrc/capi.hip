@@ -82,7 +82,6 @@ struct snp_ctx {
     bool redo_grid = false, redo_list = false;   // SNAPPIER_HIP_REDO=grid|list pins how the pre-pass's leftovers are decoded (default: by how the previous batch went)
     u32 small_team_log = 0;        // SNAPPIER_HIP_SMALL=team4|team8|team16: lanes per block (0 = the kernel's default)
     u32 slice_fragments = 262144;   // fragments per lane-compressor launch (SNAPPIER_HIP_SLICE pins it)
-    bool slice_pinned = false;
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
     DevBuf in, out, meta, work, tables, scan, small, redo;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
@@ -435,7 +434,7 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     const char* sn = getenv("SNAPPIER_HIP_SMALL_MIN");
     if (sn) c->small_min_blocks = static_cast<u32>(strtoul(sn, nullptr, 10));
     const char* sf = getenv("SNAPPIER_HIP_SLICE");
-    if (sf && atoi(sf) >= 4096) { c->slice_fragments = static_cast<u32>(atoi(sf)); c->slice_pinned = true; }
+    if (sf && atoi(sf) >= 4096) c->slice_fragments = static_cast<u32>(atoi(sf));
     const char* wm = getenv("SNAPPIER_HIP_WIN_MAX");
     if (wm) c->win_max = static_cast<u32>(strtoul(wm, nullptr, 10));
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
