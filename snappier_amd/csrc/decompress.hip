@@ -232,6 +232,9 @@ __device__ __forceinline__ u64 lds_ld64u(const u8* p) { return reinterpret_cast<
 // DS operations of one wavefront execute in order; this only stops the compiler from reordering or forwarding them.
 __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory"); }
 
+#ifndef SNP_D_TOPWAIT
+#define SNP_D_TOPWAIT 0     // 1 = the round-2 form of the batch top (vmcnt drained at a join in every batch); A/B only
+#endif
 #ifndef SNP_D_ABLATE
 #define SNP_D_ABLATE 0      // TIMING-ONLY ablations of the sub-chain front end (the output is wrong): 1 no first-pass copies, 2 no serial finish,
 #endif                      // 4 no write-out, 16 no second pass, 32 tag lists only (no batches), 64 first-pass copy sources pulled to within 1 KiB (no far reads)
@@ -977,7 +980,19 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             const u32 t = emitted + lane;
             const bool have = t < ntok;
             const u32 pos = have ? c_pos[t] : 0u;
+#if SNP_D_TOPWAIT
             const u64 q = pf_at == emitted ? q_pf : ld64u(src + wbase + pos);   // pos < L (idle lanes re-read position 0)
+#else
+            // The tag bytes were requested a batch ago (q_pf); only the first batch of a super-window loads them here.  That load's wait
+            // is kept on ITS path: merged with the prefetched value at a join, the compiler drains vmcnt in EVERY batch -- and what is
+            // still in flight at that point is the previous batch's write-out, so every batch waited ~1 k cycles for its stores to be
+            // acknowledged (the "write-out" that cost 13 % in the ablations was this wait, not the stores).
+            u64 q = q_pf;
+            if (pf_at != emitted) {
+                q = ld64u(src + wbase + pos);                           // pos < L (idle lanes re-read position 0)
+                asm volatile("" : "+v"(q));
+            }
+#endif
             const u32 c = static_cast<u32>(q) & 0xffu;
             const u32 type = c & 3u;
             const u32 hi6 = c >> 2;
