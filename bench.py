@@ -230,7 +230,10 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
-        sys.exit(f"bench.py needs an MI355X: the codec has no CPU fallback (rank {rank} of {world})")
+        print(f"bench.py needs an MI355X: the codec has no CPU fallback (rank {rank} of {world})", file=sys.stderr, flush=True)
+        if "RANK" in os.environ:
+            time.sleep(1.0)             # (under a launcher the first failing rank gets the others killed: let every rank say it first)
+        sys.exit(1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or "RANK" in os.environ             # under torch.distributed.run: always take the RCCL path
