@@ -15,6 +15,9 @@
 //      3: read + non-temporal write; 4: non-temporal read + write;
 //      5/6/7: read the entry, then write back the whole aligned 16 / 64 / 32 bytes around it (is a partially dirty
 //      sector a DRAM read-modify-write?)
+//      9: ONE returning atomic exchange per probe (round 3: what k_compress_lanes issues); 10: a non-returning atomic exchange
+//      (an insert nobody reads back: is it cheaper than the plain store of mode 2?); 11: exchange probe + every third trip a plain
+//      write-only insert into another bucket (the kernel's mix: 9 928 probes + 4 228 inserts per html-like fragment)
 template <int ILP, int MODE>
 __global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint32_t nfrag, uint32_t probes, uint32_t* __restrict__ sink, uint32_t span_log2, uint32_t interleave)
 {
@@ -34,12 +37,15 @@ __global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint
 #pragma unroll
         for (int k = 0; k < ILP; ++k) {
             h[k] = (st[k] * 0x1e35a7bdu) >> (32 - span_log2);
-            v[k] = MODE == 2 ? 0u : MODE == 4 ? __builtin_nontemporal_load(at(h[k])) : *at(h[k]);
+            v[k] = (MODE == 2 || MODE == 10) ? 0u : MODE == 4 ? __builtin_nontemporal_load(at(h[k]))
+                   : (MODE == 9 || MODE == 11) ? __hip_atomic_exchange(at(h[k]), i + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *at(h[k]);
         }
 #pragma unroll
         for (int k = 0; k < ILP; ++k) {
             if (MODE == 1 || MODE == 2 || MODE == 4) *at(h[k]) = i + k;
             if (MODE == 3) __builtin_nontemporal_store(i + k, t + h[k]);
+            if (MODE == 10) (void)__hip_atomic_exchange(at(h[k]), i + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (MODE == 11 && (i % 7u) < 3u) *at((h[k] * 40503u + 977u) & ((1u << span_log2) - 1u)) = i;   // 3 inserts per 7 probes
             if (MODE >= 5) {
                 constexpr uint32_t W = MODE == 5 ? 4 : MODE == 6 ? 16 : MODE == 8 ? 32 : 8;     // dwords
                 uint4* q = reinterpret_cast<uint4*>(t + (h[k] & ~(W - 1)));
@@ -149,6 +155,16 @@ int main(int argc, char** argv)
             run<1, 1>(tables, sink, nfrag, probes, "read+write, 1 chain per lane");
             run<1, 0>(tables, sink, nfrag, probes, "read only, 1 chain per lane");
         }
+        return 0;
+    }
+    if (argc > 3 && argv[3][0] == 'x') {     // round 3: the exchange forms
+        run<1, 1>(tables, sink, nfrag, probes, "load + store, 1 chain per lane");
+        run<1, 9>(tables, sink, nfrag, probes, "returning atomic exchange, 1 chain per lane");
+        run<1, 2>(tables, sink, nfrag, probes, "write only (plain store), 1 chain per lane");
+        run<1, 10>(tables, sink, nfrag, probes, "write only (non-returning atomic exchange), 1 chain per lane");
+        run<1, 11>(tables, sink, nfrag, probes, "exchange probes + 3 plain inserts per 7 probes, 1 chain per lane");
+        run<2, 9>(tables, sink, nfrag, probes, "returning atomic exchange, 2 chains per lane");
+        run<1, 9>(tables, sink, nfrag, probes, "returning atomic exchange, 1 chain per lane (again)");
         return 0;
     }
     if (argc > 3) {      // cache-resident sweep: few fragments, many chains
