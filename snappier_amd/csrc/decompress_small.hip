@@ -189,14 +189,15 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_small(const u8* __restr
 constexpr u32 kTeamBudget = 4608;                                       // default; the launcher may hand a wavefront more (fewer wavefronts per CU)
 constexpr u32 kTeamOutMax = 512;                                        // declared bytes a team accepts at most
 
+#define SNP_T_PARAMS                                                                                                    \
+    const u8 *__restrict__ in, const u64 *__restrict__ in_off, const u32 *__restrict__ in_len, u32 nblocks, u8 *out,    \
+        const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap, u32 *__restrict__ out_len,                   \
+        i32 *__restrict__ status, const u8 *__restrict__ chunk_type, u32 small_max, u32 *__restrict__ list,            \
+        u32 *__restrict__ ctl, u32 sub_cap, u32 budget
+#define SNP_T_ARGS in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, small_max, list, ctl, sub_cap, budget
+
 template <u32 TEAM>
-__global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restrict__ in, const u64* __restrict__ in_off,
-                                                              const u32* __restrict__ in_len, u32 nblocks, u8* out,
-                                                              const u64* __restrict__ out_off,
-                                                              const u32* __restrict__ out_cap, u32* __restrict__ out_len,
-                                                              i32* __restrict__ status, const u8* __restrict__ chunk_type,
-                                                              u32 small_max, u32* __restrict__ list, u32* __restrict__ ctl, u32 sub_cap,
-                                                              u32 budget)
+__device__ __forceinline__ void decompress_teams(SNP_T_PARAMS)
 {
     constexpr u32 kTeams = SNP_WAVE / TEAM;
     extern __shared__ __attribute__((aligned(16))) u8 t_buf[];          // `budget` bytes (dynamic LDS)
@@ -340,6 +341,22 @@ __global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(const u8* __restr
     if (live && redo && tl == 0) status[b] = kRedoStatus;
 }
 
+// Two builds of the same body.  Left to itself the kernel takes 88 VGPRs = five wavefronts per SIMD; small blocks need little LDS per
+// wavefront (<= 5 KiB: 32 wavefronts per CU fit), and then the registers are what caps the blocks in flight: held to 64 VGPRs (19 spilled
+// to scratch) it runs eight per SIMD -- 64-byte blocks 480 -> 565 GB/s, 128 B 462 -> 546, 256 B 365 -> 419 (profiles/r03x_team_occupancy.txt).
+// With more LDS per wavefront (384-512-byte blocks: 6.75-9 KiB) LDS caps the CU at 17-23 wavefronts anyway and the spills only cost
+// (512 B: 349 -> 333; a six-per-SIMD build for 384-byte blocks measured no gain), so those launches keep the uncapped build.
+template <u32 TEAM>
+__global__ __launch_bounds__(SNP_WAVE) void k_decompress_teams(SNP_T_PARAMS)
+{
+    decompress_teams<TEAM>(SNP_T_ARGS);
+}
+template <u32 TEAM>
+__global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decompress_teams_dense(SNP_T_PARAMS)
+{
+    decompress_teams<TEAM>(SNP_T_ARGS);
+}
+
 // When a batch skips the pre-pass (the previous one was all large blocks), this looks at <= 16 384 evenly spaced capacities so
 // that the host still learns what the batch was like: ctl[65] += sampled blocks of at most small_max bytes, ctl[66] += the sum of
 // the sampled capacities, ctl[67] += how many were sampled.
@@ -391,9 +408,16 @@ extern "C" hipError_t snp_launch_decompress_small(const u8* in, const u64* in_of
     }
     const char* be = getenv("SNAPPIER_HIP_TEAM_BUDGET");                // LDS bytes per wavefront (experiments; default below)
     const u32 budget = be && atoi(be) >= 1024 && atoi(be) <= 65536 ? static_cast<u32>(atoi(be)) / 16 * 16 : (team_budget ? team_budget : kTeamBudget);
+    const bool dense = budget <= 5120;                                  // 32 wavefronts per CU fit by LDS: let the registers allow them too
 #define SNP_LAUNCH_TEAMS(T)                                                                                             \
-    hipLaunchKernelGGL((k_decompress_teams<T>), dim3((nblocks + SNP_WAVE / T - 1) / (SNP_WAVE / T)), dim3(SNP_WAVE), budget, stream, \
-                       in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, lim, list, ctl, sub_cap, budget)
+    do {                                                                                                                \
+        if (dense)                                                                                                      \
+            hipLaunchKernelGGL((k_decompress_teams_dense<T>), dim3((nblocks + SNP_WAVE / T - 1) / (SNP_WAVE / T)), dim3(SNP_WAVE), budget, \
+                               stream, in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, lim, list, ctl, sub_cap, budget); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_decompress_teams<T>), dim3((nblocks + SNP_WAVE / T - 1) / (SNP_WAVE / T)), dim3(SNP_WAVE), budget, \
+                               stream, in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, status, chunk_type, lim, list, ctl, sub_cap, budget); \
+    } while (0)
     switch (tlog ? tlog : kDefaultTeamLog) {
         case 2: SNP_LAUNCH_TEAMS(4); break;
         case 3: SNP_LAUNCH_TEAMS(8); break;
