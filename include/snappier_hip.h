@@ -109,7 +109,7 @@ typedef enum snp_option {
      * 163 840 fragments; batches above 262 144 fragments run in slices).  How fast HBM serves its random traffic depends on where
      * the driver placed the buffer, so when a workspace of >= 1 GiB is first needed -- on the first large
      * snp_compress_batch of a context, and again whenever a larger batch makes it grow -- the context allocates up to
-     * SNP_OPT_TABLE_PROBE_TRIES candidates (default 12, 1 = no probe), times 5 ms of table traffic on each and keeps the fastest.
+     * SNP_OPT_TABLE_PROBE_TRIES candidates (default 16, 1 = no probe), times 5 ms of table traffic on each and keeps the fastest.
      * MEMORY BEHAVIOUR: the candidates coexist until the probe ends, within min(half of the device's free memory,
      * SNP_OPT_TABLE_PROBE_MAX_BYTES) (default 0 = no further cap); a process that shares the GPU with other allocators should set
      * the byte cap (or tries = 1) before its first large compress call.  The losers are freed before the call returns. */

@@ -566,6 +566,10 @@ emit_remainder:
 // probes on differently placed 10 GiB buffers (four discrete levels; reads alone do not vary).  So when
 // a large workspace is allocated, capi.hip allocates a few candidates, times this probe (the table traffic of the
 // compressor and nothing else, a few ms) on each and keeps the fastest.
+// Round 3: the probe issues atomic EXCHANGES, as the kernel now does.  With load + store pairs it saw two levels (5.6 / 6.25 ms) and the
+// kernel still ran anywhere between 110.4 and 117.7 ms on "fast" candidates; with exchanges it sees more (5.75-6.06 / 6.44-6.59 /
+// 7.09-7.26 ms: about one candidate in twelve is in the first group) and a candidate of the first group runs the kernel in 101-104 ms
+// instead of 110-113 (profiles/r03y_table_placement_runs*.txt).
 namespace {
 __global__ __launch_bounds__(SNP_WAVE) void k_probe_tables(u32* __restrict__ tables, u32 nblocks, u32 probes)
 {
@@ -575,8 +579,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_probe_tables(u32* __restrict__ tab
     u32 st = g * 2654435761u + 1u;
     for (u32 i = 0; i < probes; ++i) {
         const u32 h = (st * 0x1e35a7bdu) >> 18;
-        const u32 v = t[h];
-        t[h] = i;
+        const u32 v = table_swap(&t[h], i);                             // (what the kernel issues since round 3: see below)
         st = st * 1664525u + 1013904223u + v;
     }
     if (st == 0x12345678u) tables[0] = st;
