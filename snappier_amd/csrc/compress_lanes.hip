@@ -215,7 +215,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                                                             const u32* __restrict__ in_len, u32 nblocks,
                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
                                                             u32* __restrict__ out_len, i32* __restrict__ status,
-                                                            int emit_varint, u32* __restrict__ tables, int lit_blind,
+                                                            int emit_varint, const snp_table_pieces tp, int lit_blind,
                                                             const u32* __restrict__ max_len)
 {
     __shared__ u16 lut[4][256];
@@ -231,10 +231,12 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     // contiguous run, zeroed here with coalesced 16-byte stores (HashTable.cs:52) instead of a memset of the worst case.
     const u32 maxlen = *max_len;
     const u32 tstride = maxlen > 16384 ? 16384u : maxlen < 256 ? 256u : (2u << (31u - __clz(maxlen - 1)));
+    u32* wt;                                                            // this workgroup's run of tables (wave-uniform)
     {
         const u32 first = blockIdx.x * blockDim.x;
         const u32 mine = nblocks - first < blockDim.x ? nblocks - first : blockDim.x;
-        u32* wt = tables + static_cast<size_t>(first) * tstride;
+        const u32 piece = first / tp.piece_frags;                       // (piece_frags is a multiple of 64: no run straddles two pieces)
+        wt = tp.p[piece] + static_cast<size_t>(first - piece * tp.piece_frags) * tstride;
         const size_t words = static_cast<size_t>(mine) * tstride;       // a multiple of 256
         for (size_t i = static_cast<size_t>(threadIdx.x) * 4; i < words; i += static_cast<size_t>(blockDim.x) * 4)
             *reinterpret_cast<uint4*>(wt + i) = make_uint4(0, 0, 0, 0);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     c.src = in + in_off[b];
     c.dst = out + out_off[b];
     c.n = in_len[b];
-    c.table = tables + static_cast<size_t>(b) * tstride;
+    c.table = wt + static_cast<size_t>(threadIdx.x) * tstride;
     const u32 n = c.n;
     c.first4 = n >= 4 ? ld32u(c.src) : 0u;
     if (n > SNP_BLOCK_SIZE) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; return; }
@@ -571,22 +573,23 @@ emit_remainder:
 // 7.09-7.26 ms: about one candidate in twelve is in the first group) and a candidate of the first group runs the kernel in 101-104 ms
 // instead of 110-113 (profiles/r03y_table_placement_runs*.txt).
 namespace {
-__global__ __launch_bounds__(SNP_WAVE) void k_probe_tables(u32* __restrict__ tables, u32 nblocks, u32 probes)
+__global__ __launch_bounds__(SNP_WAVE) void k_probe_tables(const snp_table_pieces tp, u32 nblocks, u32 probes)
 {
     const u32 g = blockIdx.x * SNP_WAVE + threadIdx.x;
     if (g >= nblocks) return;
-    u32* t = tables + static_cast<size_t>(g) * 16384u;
+    // a set of FEWER pieces than nblocks fragments need is probed folded: the whole grid's concurrency on the pieces it has
+    u32* t = tp.p[(g / tp.piece_frags) % tp.n] + static_cast<size_t>(g % tp.piece_frags) * 16384u;
     u32 st = g * 2654435761u + 1u;
     for (u32 i = 0; i < probes; ++i) {
         const u32 h = (st * 0x1e35a7bdu) >> 18;
         const u32 v = table_swap(&t[h], i);                             // (what the kernel issues since round 3: see below)
         st = st * 1664525u + 1013904223u + v;
     }
-    if (st == 0x12345678u) tables[0] = st;
+    if (st == 0x12345678u) tp.p[0][0] = st;
 }
 }  // namespace
 
-extern "C" hipError_t snp_probe_tables(void* tables, u32 nblocks, hipStream_t stream, float* ms)
+extern "C" hipError_t snp_probe_tables(const snp_table_pieces* tp, u32 nblocks, u32 probes, hipStream_t stream, float* ms)
 {
     hipEvent_t a, b;
     hipError_t e = hipEventCreate(&a);
@@ -594,9 +597,9 @@ extern "C" hipError_t snp_probe_tables(void* tables, u32 nblocks, hipStream_t st
     e = hipEventCreate(&b);
     if (e != hipSuccess) { (void)hipEventDestroy(a); return e; }
     const u32 grid = (nblocks + SNP_WAVE - 1) / SNP_WAVE;
-    hipLaunchKernelGGL(k_probe_tables, dim3(grid), dim3(SNP_WAVE), 0, stream, static_cast<u32*>(tables), nblocks, 64u);   // warm
+    hipLaunchKernelGGL(k_probe_tables, dim3(grid), dim3(SNP_WAVE), 0, stream, *tp, nblocks, 64u);   // warm
     (void)hipEventRecord(a, stream);
-    hipLaunchKernelGGL(k_probe_tables, dim3(grid), dim3(SNP_WAVE), 0, stream, static_cast<u32*>(tables), nblocks, 768u);
+    hipLaunchKernelGGL(k_probe_tables, dim3(grid), dim3(SNP_WAVE), 0, stream, *tp, nblocks, probes);
     (void)hipEventRecord(b, stream);
     e = hipEventSynchronize(b);
     if (e == hipSuccess) e = hipEventElapsedTime(ms, a, b);
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(256) void k_max_len(const u32* __restrict__ in_len,
 
 extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                                 const u64* out_off, u32* out_len, i32* status, int variant,
-                                                int emit_varint, void* tables, u32* max_len, hipStream_t stream, int lanes_per_wave)
+                                                int emit_varint, const snp_table_pieces* tables, u32* max_len, hipStream_t stream, int lanes_per_wave)
 {
     if (nblocks == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(max_len, 0, sizeof(u32), stream);
@@ -664,7 +667,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const u32 slots = se ? static_cast<u32>(atoi(se)) : ((nblocks >= 131072 && !two_probes) ? kDefaultSlots : 2u);
 #define SNP_LAUNCH_CL(V, S)                                                                                          \
     hipLaunchKernelGGL((k_compress_lanes<V, S>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
-                       out_off, out_len, status, emit_varint, static_cast<u32*>(tables), lit_blind, max_len)
+                       out_off, out_len, status, emit_varint, *tables, lit_blind, max_len)
     if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 1); else SNP_LAUNCH_CL(SNP_HASH_CRC32C, 2); }
     else { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_MUL, 1); else SNP_LAUNCH_CL(SNP_HASH_MUL, 2); }
 #undef SNP_LAUNCH_CL

@@ -14,6 +14,16 @@ typedef int32_t i32;
 
 #define SNP_WAVE 64
 
+// The lane compressor's hash-table workspace (compress_lanes.hip): up to 16 separately allocated PIECES of `piece_frags` fragments' tables each
+// (a multiple of 64, so a workgroup's tables never straddle two pieces); fragment f's table is table f % piece_frags of piece f / piece_frags.
+// A workspace that is one allocation is one piece with piece_frags = 0xffffffc0.  Why pieces: capi.hip, ensure_tables.
+#define SNP_TABLE_PIECES_MAX 16
+struct snp_table_pieces {
+    uint32_t* p[SNP_TABLE_PIECES_MAX];
+    uint32_t piece_frags;
+    uint32_t n;
+};
+
 // Unaligned little-endian accesses.  gfx950 under HSA runs in unaligned-access mode, so a dword access at any byte
 // address is one global_load_dword / global_store_dword (the packed struct tells the compiler align = 1).
 struct __attribute__((packed)) snp_u32_unaligned { u32 v; };
