@@ -407,7 +407,10 @@ def main():
             floor_ms = nb * (9928 / 20.26e9 + 4228 / 23.57e9) * 1e3
             r_c["random_access_floor"] = {"table_probes_per_fragment": 9928, "table_inserts_per_fragment": 4228,
                                           "floor_ms": round(floor_ms, 1), "frac_of_floor": round(floor_ms / ms_c, 3),
-                                          "floor_models": "probe = dependent load + store (the round-1/2 kernel); round 3 probes with one atomic exchange"}
+                                          "floor_models": "probe = dependent load + store (the round-1/2 kernel); round 3 probes with one atomic exchange",
+                                          # the exchange probes alone at the best rate the bare table walk reaches on a workspace spread evenly over
+                                          # three kinds of device memory (30.3 ms per 163840 x 4096 exchanges, profiles/r03y_microbench_memory_kinds.jsonl)
+                                          "exchange_probes_alone_ms": round(nb * 9928 / (163840 * 4096 / 30.3e-3) * 1e3, 1)}
         line = {
             "metric": "uncompressed GB/s block compress+decompress, 64 KiB blocks",
             "value": round(total_u / (elapsed / args.steps) / 1e9, 3),
@@ -419,7 +422,7 @@ def main():
                                     "configs[4]: 10 GiB of mixed-corpus 64 KiB blocks per GPU (80 GiB at 8 GPUs), ") +
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
-                       "layout": "decompress: one block per wavefront (sub-chain tag parse over 2 KiB super-windows, 64 tags per execution batch staged in LDS); compress: one fragment per lane with HBM tables, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
+                       "layout": "decompress: one block per wavefront (sub-chain tag parse over 2 KiB super-windows, 64 tags per execution batch staged in LDS); compress: one fragment per lane, hash tables in an HBM workspace of 16 pieces spread over the kinds of device memory, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,

@@ -84,8 +84,8 @@ snp_status snp_ctx_synchronize(snp_ctx* ctx);
 /* Introspection for tests and tuning: how often this context took a code path since it was created.
  * which: 0 = large single blocks decoded one wavefront per 64 KiB fragment (snp_try_decompress, tag index),
  *        1 = large single blocks that fell back to the single-wavefront decoder (foreign / malformed streams),
- *        2 = microseconds the chosen hash-table workspace took in the placement probe (0: no probe ran),
- *        3 = workspace candidates that were probed. */
+ *        2 = microseconds the chosen hash-table workspace took in the placement probe (512 table-walk probes per fragment; 0: no search ran),
+ *        3 = candidate pieces the workspace search allocated. */
 uint64_t snp_ctx_counter(const snp_ctx* ctx, int which);
 
 /* Per-context configuration.  A library loaded into a long-running service is configured through these, per context and at any
@@ -107,10 +107,13 @@ typedef enum snp_option {
     SNP_OPT_COMPRESS_WINDOW_MAX_BATCH = 5,   /* default 16384 */
     /* The lane compressor keeps 64 KiB of hash table per fragment of a launch in an HBM workspace the context owns (10.7 GB for
      * 163 840 fragments; batches above 262 144 fragments run in slices).  How fast HBM serves its random traffic depends on where
-     * the driver placed the buffer, so when a workspace of >= 1 GiB is first needed -- on the first large
-     * snp_compress_batch of a context, and again whenever a larger batch makes it grow -- the context allocates up to
-     * SNP_OPT_TABLE_PROBE_TRIES candidates (default 16, 1 = no probe), times 5 ms of table traffic on each and keeps the fastest.
-     * MEMORY BEHAVIOUR: the candidates coexist until the probe ends, within min(half of the device's free memory,
+     * the driver placed the memory: device memory consists of regions of several kinds, and the traffic runs 20-25 % faster spread
+     * evenly over two or three kinds than confined to one.  So when a workspace of >= 1 GiB is first needed -- on the
+     * first large snp_compress_batch of a context, and again whenever a larger batch makes it grow -- the context builds it from up to
+     * 16 separately allocated pieces chosen by measurement: candidate pieces (1/16 of the workspace each) are allocated 16 at a time
+     * and probed in pairs (5 ms per probe) until a balanced set exists -- typically 48 candidates = three workspaces' worth for half a
+     * second -- or SNP_OPT_TABLE_PROBE_TRIES workspaces' worth of candidates (default 16, 1 = no search: one allocation) have been tried.
+     * MEMORY BEHAVIOUR: the candidates coexist until the search ends, within min(half of the device's free memory,
      * SNP_OPT_TABLE_PROBE_MAX_BYTES) (default 0 = no further cap); a process that shares the GPU with other allocators should set
      * the byte cap (or tries = 1) before its first large compress call.  The losers are freed before the call returns. */
     SNP_OPT_TABLE_PROBE_TRIES = 6,

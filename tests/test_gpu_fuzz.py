@@ -362,3 +362,54 @@ def test_crc32c_table_free_kernel_equals_the_table_kernel_and_the_oracle():
         framed = S.frame_encode(payload, cd.ctx)
         assert framed == O.frame_encode(payload) and S.frame_decode(framed, cd.ctx) == payload
     cd.ctx.set_option(N.OPT_CRC_TABLE_FREE, 0)
+
+
+def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
+    """A lane-compressor batch whose hash-table workspace is >= 1 GiB runs on up to 16 separately allocated pieces picked by the
+    placement search (capi.hip, PieceSearch); below that, with SNP_OPT_TABLE_PROBE_TRIES = 1, or when the byte cap leaves no room for
+    spare candidates, on plain allocations.  All of them must return the oracle's bytes: every block compared by length and CRC across
+    the contexts, the blocks either side of every piece boundary (and the ragged tail) byte for byte against the oracle; a second,
+    larger batch makes the searched workspace grow (pieces freed, search repeated)."""
+    N = S._native
+    from snappier_amd import datagen as SD
+    html = read_testdata("html")
+    results = {}
+    for nb in (20001, 36000):                                          # 1.3 GB and 2.4 GB of tables: 16 pieces of 1280 / 2304 fragments
+        raw = SD.html_like_blocks(html, 7, nb, "cuda")
+        lens = torch.full((nb,), 65536, dtype=torch.int32, device="cuda")
+        lens[-1] = 777
+        lens[nb // 2] = 0
+        off = torch.arange(nb, dtype=torch.int64, device="cuda") * 65536
+        sigs = []
+        for name in ("searched", "one_allocation", "capped"):
+            cd = results.setdefault(name, SB.BlockCodec(0, O.HASH_CRC32C))
+            if name == "one_allocation":
+                cd.ctx.set_option(N.OPT_TABLE_PROBE_TRIES, 1)
+            if name == "capped":
+                cd.ctx.set_option(N.OPT_TABLE_PROBE_MAX_BYTES, 1 << 30)
+            cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, 2)
+            out, out_off, out_len, st = cd.compress(raw, off, lens)
+            torch.cuda.synchronize()
+            assert int((st != 0).sum()) == 0
+            crcs = cd.crc32c(out, out_off, out_len)
+            sigs.append((name, out_len.cpu().numpy(), crcs.cpu().numpy()))
+            if name == "searched":
+                assert cd.ctx.counter(3) >= 32 and cd.ctx.counter(2) > 0, "the search did not run"
+                piece = ((nb + 15) // 16 + 63) // 64 * 64
+                check = sorted({b for k in range(1, 16) for b in (k * piece - 1, k * piece) if b < nb} | {0, nb // 2, nb - 2, nb - 1})
+                idx = torch.tensor(check, device="cuda")
+                sub = torch.cat([raw[int(off[b]): int(off[b]) + int(lens[b])] for b in check]).cpu().numpy()
+                sub_len = lens[idx].cpu().numpy().astype(np.uint32)
+                sub_off = np.concatenate([[0], np.cumsum(sub_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+                ref, ref_off, ref_len, ref_st = O.compress_batch(sub, sub_off, sub_len, O.HASH_CRC32C, THREADS)
+                outh_len = out_len[idx].cpu().numpy()
+                assert (ref_st == 0).all() and (outh_len == ref_len).all()
+                for j, b in enumerate(check):
+                    got = out[int(out_off[b]): int(out_off[b]) + int(outh_len[j])].cpu().numpy()
+                    assert np.array_equal(got, ref[int(ref_off[j]): int(ref_off[j]) + int(ref_len[j])]), f"block {b} (piece boundary) of {nb}"
+            else:
+                assert cd.ctx.counter(3) in (0, 16), name          # no spare candidates: nothing to search
+        for name, l, c in sigs[1:]:
+            assert (l == sigs[0][1]).all() and (c == sigs[0][2]).all(), f"{name} differs from the searched workspace at {nb} blocks"
+        del raw
+    log_session(test="hash_table_workspace_in_pieces", blocks=[20001, 36000], contexts=["searched", "one_allocation", "capped"], result="all equal")
