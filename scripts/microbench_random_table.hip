@@ -72,6 +72,25 @@ __global__ __launch_bounds__(64) void k_walk(uint32_t* __restrict__ tables, uint
 // Round 3: the same exchange walk over a workspace made of PIECES (separate allocations): lane g's table is table (g % per_piece) of
 // piece (g / per_piece) % npieces -- per_piece < nfrag / npieces folds several lanes onto one table, which probes ONE small candidate with
 // the whole grid's concurrency.
+// KIND 0: atomic exchange (the compressor's probe), 1: dependent load only, 2: store only (nothing read back), 3: dependent load + store
+template <int KIND>
+__global__ __launch_bounds__(64) void k_walk_pieces_t(uint32_t* const* __restrict__ pieces, uint32_t npieces, uint32_t per_piece, uint32_t nfrag,
+                                                      uint32_t probes, uint32_t* __restrict__ sink)
+{
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= nfrag) return;
+    uint32_t* t = pieces[(g / per_piece) % npieces] + (static_cast<uint64_t>(g % per_piece) << 14);
+    uint32_t st = g * 2654435761u + 1u;
+    for (uint32_t i = 0; i < probes; ++i) {
+        const uint32_t h = (st * 0x1e35a7bdu) >> 18;
+        uint32_t v = 0;
+        if (KIND == 0) v = __hip_atomic_exchange(t + h, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (KIND == 1 || KIND == 3) v = t[h];
+        if (KIND == 2 || KIND == 3) t[h] = i;
+        st = st * 1664525u + 1013904223u + v;
+    }
+    if (st == 0x12345678u) sink[0] = st;
+}
 __global__ __launch_bounds__(64) void k_walk_pieces(uint32_t* const* __restrict__ pieces, uint32_t npieces, uint32_t per_piece, uint32_t nfrag,
                                                     uint32_t probes, uint32_t* __restrict__ sink)
 {
@@ -85,6 +104,21 @@ __global__ __launch_bounds__(64) void k_walk_pieces(uint32_t* const* __restrict_
         st = st * 1664525u + 1013904223u + v;
     }
     if (st == 0x12345678u) sink[0] = st;
+}
+template <int KIND>
+static float time_pieces_t(uint32_t* const* d_ptrs, uint32_t npieces, uint32_t per_piece, uint32_t nfrag, uint32_t probes, uint32_t* sink)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL(k_walk_pieces_t<KIND>, dim3((nfrag + 63) / 64), dim3(64), 0, 0, d_ptrs, npieces, per_piece, nfrag, probes, sink);
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        CK(hipEventElapsedTime(&ms, a, b));
+    }
+    return ms;
 }
 
 static float time_pieces(uint32_t* const* d_ptrs, uint32_t npieces, uint32_t per_piece, uint32_t nfrag, uint32_t probes, uint32_t* sink)
@@ -338,6 +372,26 @@ int main(int argc, char** argv)
                 if (i == j) for (uint32_t k = 0; k < cand.size(); ++k) if (kind[k] == static_cast<int>(i + 1) && k != refs[i]) { b = k; break; }
                 printf("{\"case\": \"reference pair\", \"kinds\": [%zu, %zu], \"ms\": %.3f}\n", i + 1, j + 1, probe({refs[i], b}, 512));
             }
+        // which KIND OF ACCESS sees the kinds of memory?  16 pieces of kind 1 against 8 + 8 of kinds 1 and 2: exchanges, loads only, stores only, load + store
+        {
+            std::vector<std::vector<uint32_t>> mem(refs.size() + 1);
+            for (uint32_t k = 0; k < cand.size(); ++k) if (kind[k] >= 1) mem[kind[k]].push_back(k);
+            if (refs.size() >= 2 && mem[1].size() >= parts && mem[2].size() >= parts / 2) {
+                std::vector<uint32_t> one(mem[1].begin(), mem[1].begin() + parts), two;
+                for (uint32_t i = 0; i < parts / 2; ++i) { two.push_back(mem[1][i]); two.push_back(mem[2][i]); }
+                auto run4 = [&](const char* name, const std::vector<uint32_t>& idx) {
+                    std::vector<uint32_t*> ptrs;
+                    for (uint32_t i : idx) ptrs.push_back(cand[i]);
+                    CK(hipMemcpy(d_ptrs, ptrs.data(), ptrs.size() * sizeof(uint32_t*), hipMemcpyHostToDevice));
+                    const uint32_t np = static_cast<uint32_t>(ptrs.size());
+                    printf("{\"case\": \"access kinds on %s\", \"probes\": %u, \"exchange_ms\": %.3f, \"load_only_ms\": %.3f, \"store_only_ms\": %.3f, \"load_store_ms\": %.3f}\n", name, probes,
+                           time_pieces_t<0>(d_ptrs, np, per_piece, nfrag, probes, sink), time_pieces_t<1>(d_ptrs, np, per_piece, nfrag, probes, sink),
+                           time_pieces_t<2>(d_ptrs, np, per_piece, nfrag, probes, sink), time_pieces_t<3>(d_ptrs, np, per_piece, nfrag, probes, sink));
+                };
+                run4("16 pieces of one kind", one);
+                run4("8 + 8 pieces of two kinds", two);
+            }
+        }
         // composed workspaces: 16 pieces of one kind, and 16 pieces drawn evenly from all kinds
         std::vector<std::vector<uint32_t>> members(refs.size() + 1);
         for (uint32_t k = 0; k < cand.size(); ++k) if (kind[k] >= 0) members[kind[k]].push_back(k);
