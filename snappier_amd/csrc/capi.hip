@@ -379,6 +379,7 @@ struct snp_ctx {
             chint_pending = false;
             chint_small = chint[0] != 0 && chint[0] <= 512;
             chint_mid = chint[0] != 0 && chint[0] <= 4096;
+            chint_tiny = (chint[0] > 80 && chint[0] <= 768) ? static_cast<int>((chint[0] + 15u) >> 4) : 0;   // LDS slot of the input-in-LDS launch, in 16-byte units
         } else {
             (void)hipGetLastError();
         }
@@ -392,7 +393,7 @@ struct snp_ctx {
         // batch is assumed to be alike; results do not depend on it.
         // (bit 8: two speculative probes per trip whatever the batch size -- fragments of at most 4 KiB are latency-bound, not request-bound:
         //  1 KiB blocks 45.6 GB/s with one exchange probe, 48.3-49.0 with two probes, profiles/r03p_small_compress_sweep.jsonl)
-        const int lanes_per_wave = (chint_small ? 32 : 0) | (chint_mid ? 256 : 0);
+        const int lanes_per_wave = (chint_small ? 32 : 0) | (chint_mid ? 256 : 0) | (chint_tiny << 9);   // bits 9-14: slot size of the launch with the input in LDS, which then goes first (compress_lanes.hip, SMALL)
         for (u32 first = 0; first < nblocks; first += kSlice) {
             const u32 cnt = nblocks - first < kSlice ? nblocks - first : kSlice;
             if (!check(snp_launch_compress_lanes(d_in, in_off + first, in_len + first, cnt, d_out, out_off + first,
@@ -412,6 +413,7 @@ struct snp_ctx {
     u32* chint = nullptr;                                // pinned: the longest fragment of the previous lane-compressor launch
     hipEvent_t chint_ev = nullptr;
     bool chint_pending = false, chint_small = false, chint_mid = false;
+    int chint_tiny = 0;
     bool chint_ready()
     {
         if (!chint && hipHostMalloc(reinterpret_cast<void**>(&chint), 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); chint = nullptr; return false; }

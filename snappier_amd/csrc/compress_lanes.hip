@@ -210,13 +210,19 @@ __device__ __forceinline__ void stage_drain(const LaneCtx& c, OutStage& st, u32 
     st.flushed = op;
 }
 
-template <int VARIANT, u32 kSlots>
+// SMALL = true: the launch for batches whose LONGEST fragment is at most `small_max` bytes (256-byte blocks: a handful of probes per
+// fragment).  Such a launch is bound by the texture path: every step of a lane is ~7 scattered vector-memory instructions at 40-57 cycles
+// each (PMC, profiles/r03y_small_compress_pmc.txt: TA busy 80 %).  With the fragment's BYTES copied into LDS first (small_max + 16 per lane,
+// dynamic), the input, candidate and literal reads of a step are LDS reads and only the table accesses and the output stay on the
+// texture path.  Whether a batch qualifies is known only on the device (max_len), so the host launches this kernel in front of the
+// general one whenever the previous batch was small, and each of the two returns at once if the batch is not its own.
+template <int VARIANT, u32 kSlots, bool SMALL>
 __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                             const u32* __restrict__ in_len, u32 nblocks,
                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
                                                             u32* __restrict__ out_len, i32* __restrict__ status,
                                                             int emit_varint, const snp_table_pieces tp, int lit_blind,
-                                                            const u32* __restrict__ max_len)
+                                                            const u32* __restrict__ max_len, u32 small_max)
 {
     __shared__ u16 lut[4][256];
     if (VARIANT == SNP_HASH_CRC32C) {
@@ -224,12 +230,14 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
             lut[e >> 8][e & 255u] = static_cast<u16>(crc_step32((e & 255u) << (8 * (e >> 8))) & 0x7ffeu);
         __syncthreads();
     }
-    __shared__ u8 s_out[SNP_WAVE * kStageStride];
+    __shared__ u8 s_out[SMALL ? 16 : SNP_WAVE * kStageStride];        // (SMALL: the stage lives behind the input slots in dynamic LDS, sized by the launch's lanes per wavefront)
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     // Table stride = CalculateTableSize of the LONGEST fragment of the batch (HashTable.cs:57-71; k_max_len ran before this
     // launch): a batch of 256-byte blocks keeps 1 KiB of table per fragment, not 64 KiB.  The wavefront's tables are one
     // contiguous run, zeroed here with coalesced 16-byte stores (HashTable.cs:52) instead of a memset of the worst case.
     const u32 maxlen = *max_len;
+    if (SMALL ? maxlen > small_max : (small_max != 0 && maxlen <= small_max)) return;   // the twin launch's batch
+    extern __shared__ __attribute__((aligned(16))) u8 s_dyn[];         // SMALL: blockDim x (small_max + 16) bytes of input
     const u32 tstride = maxlen > 16384 ? 16384u : maxlen < 256 ? 256u : (2u << (31u - __clz(maxlen - 1)));
     u32* wt;                                                            // this workgroup's run of tables (wave-uniform)
     {
@@ -245,14 +253,27 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     if (b >= nblocks) return;
     const bool staged = (lit_blind & 16) != 0;
     const bool t_swap = kSlots == 1 && (lit_blind & 64) != 0;          // probe + insert as one atomic exchange (one probe per trip only)
-    OutStage stg{s_out + threadIdx.x * kStageStride, 0};
+    OutStage stg{(SMALL ? s_dyn + blockDim.x * (small_max + 16u) : s_out) + threadIdx.x * kStageStride, 0};
 
     LaneCtx c;
-    c.src = in + in_off[b];
     c.dst = out + out_off[b];
     c.n = in_len[b];
     c.table = wt + static_cast<size_t>(threadIdx.x) * tstride;
     const u32 n = c.n;
+    if constexpr (SMALL) {                                              // the fragment's bytes into this lane's LDS slot (n <= small_max)
+        const u8* g = in + in_off[b];
+        u8* mine = s_dyn + threadIdx.x * (small_max + 16u);
+        u32 i = 0;
+        for (; i + 16 <= n; i += 16) {
+            const snp_u128_unaligned q = *reinterpret_cast<const snp_u128_unaligned*>(g + i);
+            *reinterpret_cast<uint4*>(mine + i) = make_uint4(q.v[0], q.v[1], q.v[2], q.v[3]);
+        }
+        for (; i + 4 <= n; i += 4) *reinterpret_cast<u32*>(mine + i) = ld32u(g + i);
+        for (; i < n; ++i) mine[i] = g[i];
+        c.src = mine;
+    } else {
+        c.src = in + in_off[b];
+    }
     c.first4 = n >= 4 ? ld32u(c.src) : 0u;
     if (n > SNP_BLOCK_SIZE) { out_len[b] = 0; status[b] = SNP_ERR_BAD_ARG; return; }
 
@@ -645,6 +666,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
     const char* env = getenv("SNAPPIER_HIP_LANES_PER_WAVE");
     const bool two_probes = (lanes_per_wave & 256) != 0;               // the context's hint: small fragments (capi.hip)
+    const u32 small_hint = ((static_cast<u32>(lanes_per_wave) >> 9) & 63u) << 4;   // ... and, when they are small enough for it, the LDS slot size of the SMALL launch
     lanes_per_wave &= 255;
     u32 per = env ? static_cast<u32>(atoi(env)) : lanes_per_wave ? static_cast<u32>(lanes_per_wave) : (nblocks >= 131072 ? 64u : nblocks >= 8192 ? 32u : 16u);   // measured: scripts/sweep_layouts.py
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
@@ -665,9 +687,32 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // (... and for batches of SMALL fragments at any size -- bit 8 of lanes_per_wave is the context's hint for them: they are latency-bound, not
     // request-bound: 256-byte blocks 40.7 GB/s with one exchange probe per trip, 46.5 with two speculative probes, profiles/r03p_small_compress_sweep.jsonl)
     const u32 slots = se ? static_cast<u32>(atoi(se)) : ((nblocks >= 131072 && !two_probes) ? kDefaultSlots : 2u);
+    // The context's hint: the longest fragment of the previous launch, rounded up to 16 bytes, when it lay in (80, 768] (bits 9-14 of
+    // lanes_per_wave; measured, profiles/r03y_small_compress_lds_input_sweep.txt: 96 B 41.0 -> 42.8 GB/s, 128 B 42.2 -> 47.2, 256 B 48.1 -> 60.1-61.6,
+    // 512 B 47.8 -> 60.7-62.6, 768 B 49.6 -> 51.3; 64 B and 1 KiB lose).  The launch with the input in LDS goes first; each of the two launches
+    // checks max_len on the device and returns if the batch is the other one's.  SNAPPIER_HIP_CL_SMALL=0 never launches it, =<bytes> forces
+    // its slot size; SNAPPIER_HIP_CL_SMALL_PER = its lanes per wavefront.
+    const char* sm = getenv("SNAPPIER_HIP_CL_SMALL");
+    u32 small_max = sm ? (static_cast<u32>(atoi(sm)) + 15u) & ~15u : small_hint;
+    if (small_max > 2048) small_max = 0;
+    if (small_max) {
+        const char* sp = getenv("SNAPPIER_HIP_CL_SMALL_PER");
+        u32 sper = sp ? static_cast<u32>(atoi(sp)) : 32u;
+        if (sper != 64 && sper != 32 && sper != 16) sper = 32;
+        const u32 sgrid = (nblocks + sper - 1) / sper;
+        const u32 dyn = sper * (small_max + 16u + kStageStride);
+#define SNP_LAUNCH_SMALL(V)                                                                                                                         \
+    do {                                                                                                                                            \
+        if (dyn > 48u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_compress_lanes<V, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn)); \
+        hipLaunchKernelGGL((k_compress_lanes<V, 2, true>), dim3(sgrid), dim3(sper), dyn, stream, in, in_off, in_len, nblocks, out, out_off, out_len, status, \
+                           emit_varint, *tables, lit_blind, max_len, small_max);                                                                    \
+    } while (0)
+        if (variant == SNP_HASH_CRC32C) SNP_LAUNCH_SMALL(SNP_HASH_CRC32C); else SNP_LAUNCH_SMALL(SNP_HASH_MUL);
+#undef SNP_LAUNCH_SMALL
+    }
 #define SNP_LAUNCH_CL(V, S)                                                                                          \
-    hipLaunchKernelGGL((k_compress_lanes<V, S>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
-                       out_off, out_len, status, emit_varint, *tables, lit_blind, max_len)
+    hipLaunchKernelGGL((k_compress_lanes<V, S, false>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
+                       out_off, out_len, status, emit_varint, *tables, lit_blind, max_len, small_max)
     if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 1); else SNP_LAUNCH_CL(SNP_HASH_CRC32C, 2); }
     else { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_MUL, 1); else SNP_LAUNCH_CL(SNP_HASH_MUL, 2); }
 #undef SNP_LAUNCH_CL

@@ -413,3 +413,61 @@ def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
             assert (l == sigs[0][1]).all() and (c == sigs[0][2]).all(), f"{name} differs from the searched workspace at {nb} blocks"
         del raw
     log_session(test="hash_table_workspace_in_pieces", blocks=[20001, 36000], contexts=["searched", "one_allocation", "capped"], result="all equal")
+
+
+@pytest.mark.parametrize("variant", [O.HASH_CRC32C, O.HASH_MUL])
+def test_small_fragment_launch_with_input_in_lds_equals_oracle(variant, monkeypatch):
+    """Batches whose longest fragment is small take a second form of the lane compressor (fragment bytes in LDS, compress_lanes.hip
+    SMALL) -- chosen from the PREVIOUS launch's longest fragment, verified on the device against this launch's.  Sequences that
+    exercise every combination: no hint yet (general launch), hint and batch agree (LDS launch), a batch with a longer fragment after a
+    small hint (the LDS launch must step aside), a smaller batch after a larger hint, forced slot sizes; ragged lengths 0..limit incl.
+    the 14/15/16-byte boundary of the reference's short-input path.  Every block byte-equal to the oracle."""
+    N = S._native
+    text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
+    rng = np.random.default_rng(77 + variant)
+    cd = SB.BlockCodec(0, variant)
+    cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, 2)                       # the lane compressor whatever the batch size
+
+    def batch(limit, count, exact=False):
+        blocks = []
+        for _ in range(count):
+            n = limit if exact else int(rng.choice([0, 1, 3, 14, 15, 16, 17, 31, limit - 1, limit])) if rng.integers(0, 4) == 0 else int(rng.integers(0, limit + 1))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                b = rng.integers(0, 256, n, dtype=np.uint8)
+            elif kind == 1:
+                b = rng.integers(0, int(rng.integers(1, 4)), n, dtype=np.uint8)
+            else:
+                s0 = int(rng.integers(0, len(text) - n - 1))
+                b = text[s0: s0 + n].copy()
+                if n and kind == 3:
+                    b[n // 2:] = b[: n - n // 2]                       # a long match inside the fragment
+            blocks.append(b)
+        blocks[int(rng.integers(0, count))] = np.resize(text[100: 100 + limit], limit).copy()   # the longest fragment is `limit` for sure
+        return blocks
+
+    def check(blocks, what):
+        data, off, lens = batch_of(blocks)
+        ref, ref_off, ref_len, ref_st = O.compress_batch(data, off.astype(np.uint64), lens.astype(np.uint32), variant, THREADS)
+        out, out_off, out_len, status = cd.compress(dev(data), dev(off), dev(lens))
+        torch.cuda.synchronize()
+        out, out_off, out_len = out.cpu().numpy(), out_off.cpu().numpy(), out_len.cpu().numpy()
+        assert (status.cpu().numpy() == 0).all() and (ref_st == 0).all(), what
+        assert (out_len == ref_len).all(), f"{what}: lengths differ at blocks {np.nonzero(out_len != ref_len)[0][:8]}"
+        for b in range(len(blocks)):
+            assert np.array_equal(out[out_off[b]: out_off[b] + out_len[b]], ref[int(ref_off[b]): int(ref_off[b]) + int(ref_len[b])]), f"{what}: block {b} (len {lens[b]})"
+        return len(blocks)
+
+    compared = 0
+    for step, limit in enumerate([256, 256, 200, 512, 512, 4096, 96, 96, 768, 768, 1024, 300, 300, 65536, 256]):
+        compared += check(batch(limit, 3000 if limit <= 4096 else 64), f"step {step}: fragments up to {limit} bytes")
+    for forced in ("0", "256", "128", "2000"):                           # the debug override: never / slot sizes that fit, do not fit, exceed the cap
+        monkeypatch.setenv("SNAPPIER_HIP_CL_SMALL", forced)
+        for limit in (256, 130):
+            compared += check(batch(limit, 2000), f"SNAPPIER_HIP_CL_SMALL={forced}, fragments up to {limit}")
+    monkeypatch.delenv("SNAPPIER_HIP_CL_SMALL")
+    for per in ("16", "64"):
+        monkeypatch.setenv("SNAPPIER_HIP_CL_SMALL_PER", per)
+        for limit in (256, 256):
+            compared += check(batch(limit, 2000, exact=(per == "64")), f"{per} lanes per wavefront")
+    log_session(test="small_fragment_launch_with_input_in_lds", hash_variant=variant, blocks_compared=compared, result="all equal")
