@@ -60,6 +60,7 @@ internal static unsafe class NativeMethods
     [DllImport(Lib, CallingConvention = Cc)] internal static extern ulong snp_ctx_counter(IntPtr ctx, int which);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_ctx_set_option(IntPtr ctx, int option, long value);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_ctx_get_option(IntPtr ctx, int option, out long value);
+    [DllImport(Lib, CallingConvention = Cc)] internal static extern SnpStatus snp_ctx_reserve_compress(IntPtr ctx, uint nfragments);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern IntPtr snp_status_string(int status);
     [DllImport(Lib, CallingConvention = Cc)] internal static extern IntPtr snp_version();
 

@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
         "snp_ctx_counter": (u64, [vp, i32]),
         "snp_ctx_set_option": (i32, [vp, i32, i64]),
         "snp_ctx_get_option": (i32, [vp, i32, C.POINTER(i64)]),
+        "snp_ctx_reserve_compress": (i32, [vp, u32]),
         "snp_status_string": (C.c_char_p, [i32]),
         "snp_version": (C.c_char_p, []),
         "snp_max_compressed_length": (i64, [i64]),

@@ -46,6 +46,13 @@ class Context:
         if st != N.OK:
             raise ValueError(f"snp_ctx_set_option({option}, {value}): {N.status_string(st)}")
 
+    def reserve_compress(self, nfragments: int):
+        """snp_ctx_reserve_compress: build the lane compressor's hash-table workspace for batches of up to `nfragments` fragments now
+        (a service's start-up, before its buffers crowd the device) instead of on the first large compress call."""
+        st = N.lib().snp_ctx_reserve_compress(self._h, int(nfragments))
+        if st != N.OK:
+            raise InvalidOperationException(f"snp_ctx_reserve_compress({nfragments}): {N.status_string(st)}: {N.lib().snp_ctx_last_error(self._h).decode()}")
+
     def get_option(self, option: int) -> int:
         v = C.c_int64(0)
         st = N.lib().snp_ctx_get_option(self._h, option, C.byref(v))

@@ -654,6 +654,15 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
 
 uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 4) ? c->counters[which] : 0; }
 
+snp_status snp_ctx_reserve_compress(snp_ctx* c, uint32_t nfragments)
+{
+    if (!c) return SNP_ERR_BAD_ARG;
+    if (nfragments == 0) return SNP_OK;
+    DevGuard dg(c);
+    if (!dg.ok) return SNP_ERR_DEVICE;
+    return c->ensure_tables(nfragments < c->slice_fragments ? nfragments : c->slice_fragments) ? SNP_OK : SNP_ERR_DEVICE;
+}
+
 snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
 {
     if (!c) return SNP_ERR_BAD_ARG;

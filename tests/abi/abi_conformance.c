@@ -44,6 +44,7 @@ typedef int32_t (*fn_ctx_synchronize)(void*);
 typedef uint64_t (*fn_ctx_counter)(const void*, int32_t);
 typedef int32_t (*fn_ctx_set_option)(void*, int32_t, int64_t);
 typedef int32_t (*fn_ctx_get_option)(const void*, int32_t, int64_t*);
+typedef int32_t (*fn_ctx_reserve)(void*, uint32_t);
 typedef const char* (*fn_status_string)(int32_t);
 typedef const char* (*fn_version)(void);
 typedef int64_t (*fn_len)(int64_t);
@@ -98,7 +99,7 @@ int main(int argc, char** argv)
     /* every DllImport of NativeMethods.cs must resolve */
     static const char* all[] = {
         "snp_ctx_create", "snp_ctx_destroy", "snp_ctx_set_stream", "snp_ctx_last_error", "snp_ctx_synchronize", "snp_ctx_counter",
-        "snp_ctx_set_option", "snp_ctx_get_option", "snp_status_string", "snp_version", "snp_max_compressed_length", "snp_max_fragment_compressed_length",
+        "snp_ctx_set_option", "snp_ctx_get_option", "snp_ctx_reserve_compress", "snp_status_string", "snp_version", "snp_max_compressed_length", "snp_max_fragment_compressed_length",
         "snp_get_uncompressed_length", "snp_try_compress", "snp_try_decompress", "snp_try_compress_segments", "snp_try_decompress_segments", "snp_crc32c", "snp_frame_max_encoded_length",
         "snp_frame_encode", "snp_frame_decoded_length", "snp_frame_decode", "snp_compress_batch", "snp_decompress_batch",
         "snp_crc32c_batch", "snp_concat_batch", "snp_frame_encode_workspace", "snp_frame_encode_device",
@@ -179,6 +180,12 @@ int main(int argc, char** argv)
         EXPECT(set_option(ctx, SNP_OPT_TABLE_PROBE_TRIES, 0) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_TABLE_PROBE_TRIES, 3) == SNP_OK);
         EXPECT(get_option(ctx, SNP_OPT_SMALL_BLOCK_MAX, &v) == SNP_OK && v == 512);
         EXPECT(set_option(ctx, 999, 1) == SNP_ERR_BAD_ARG && get_option(ctx, 999, &v) == SNP_ERR_BAD_ARG && get_option(ctx, SNP_OPT_FENCED, NULL) == SNP_ERR_BAD_ARG);
+    }
+    {
+        /* GpuContext.ReserveCompress: nothing to do for 0 fragments, a small workspace for a few, a null context is refused */
+        fn_ctx_reserve reserve = (fn_ctx_reserve)must(lib, "snp_ctx_reserve_compress");
+        EXPECT(reserve(NULL, 16) == SNP_ERR_BAD_ARG);
+        EXPECT(reserve(ctx, 0) == SNP_OK && reserve(ctx, 64) == SNP_OK && reserve(ctx, 32) == SNP_OK);
     }
 
     /* ---- device: the sequences of Snappy.cs ------------------------------------------------------------------ */
