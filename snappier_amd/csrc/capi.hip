@@ -14,6 +14,7 @@
 #include <utility>
 #include <vector>
 
+#include "piece_search.h"
 #include "snp_device.h"
 
 extern "C" {
@@ -57,172 +58,7 @@ struct DevBuf {
 
 inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
-// ---- where the lane compressor's hash tables live ---------------------------------------------------------------------------------------
-// The kernel is bound by the rate at which HBM serves random 4-byte exchanges spread over the whole 64 KiB-per-fragment workspace, and that
-// rate depends on WHERE the driver placed the memory.  Measured (scripts/microbench_random_table.hip modes m, g and k,
-// profiles/r03y_microbench_*.jsonl): device memory consists of regions of tens of GiB of (at least) three KINDS.  Traffic
-// confined to one kind runs the table walk in 38.0 ms per 4096 probes, spread evenly over two kinds in 31.9 ms, over three in 30.3 ms; the kind
-// is a stable property of where an allocation landed, and one 10 GiB hipMalloc usually lies inside one region (34.5-38.2 ms).  Two 0.6 GiB
-// pieces probed TOGETHER tell whether they share a kind: 4.31-4.36 ms per 512 probes if they do, 3.65-3.68 ms if they do not.
-// So a GiB-sized workspace is built from up to 16 separately allocated pieces, chosen by measurement:
-//   * candidates are allocated 16 at a time; the most one-sided piece of the first round (slowest probed alone) is the first REFERENCE;
-//   * every candidate is probed paired with every reference; share(r, k) = how much of candidate k is of reference r's kind, from where the
-//     pair's time falls between the two levels; a candidate that no reference explains becomes the next reference (up to four);
-//   * the 16 pieces are picked greedily so that the largest per-kind sum stays smallest; candidates keep coming until the largest kind's
-//     share of the set is <= 0.36 (three kinds evenly; <= 0.52, two kinds, from the third round on) or `max_cand` (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, half of free memory, the
-//     byte cap) is reached; a short hill climb on the COMPOSED probe polishes the result.
-// Cost: 0.3-3 s and the candidates' memory, once, at the first large compress call of a context; the losers are freed before it returns.
-struct PieceSearch {
-    hipStream_t stream;
-    u32 nblocks, piece_frags, n;
-    size_t piece_bytes, max_cand;
-    bool dbg;
-    std::vector<u32*> cand;
-    std::vector<float> alone;                    // probed alone (0 = not measured)
-    std::vector<u32> refs;
-    std::vector<std::vector<float>> pair_ms;     // [reference][candidate]
-    float lo = 0;                                // pair level of two pieces that share nothing
-    u32 trials = 0;
-    static constexpr float kSameOverDisjoint = 1.18f;   // 4.33 / 3.67
-
-    float probe(const std::vector<u32>& set)     // ms of 512 table-walk probes per fragment on these candidates (folded when fewer than n)
-    {
-        snp_table_pieces t{};
-        for (size_t i = 0; i < set.size(); ++i) t.p[i] = cand[set[i]];
-        t.piece_frags = piece_frags;
-        t.n = static_cast<u32>(set.size());
-        float ms = 1e30f;
-        if (snp_probe_tables(&t, nblocks, 512u, stream, &ms) != hipSuccess) { (void)hipGetLastError(); ms = 1e30f; }
-        ++trials;
-        return ms;
-    }
-    float alone_ms(u32 k)
-    {
-        if (alone[k] == 0) alone[k] = probe({k});
-        return alone[k];
-    }
-    bool grow()
-    {
-        const size_t before = cand.size();
-        for (u32 k = 0; k < n && cand.size() < max_cand; ++k) {
-            void* q = nullptr;
-            if (hipMalloc(&q, piece_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-            cand.push_back(static_cast<u32*>(q));
-        }
-        alone.resize(cand.size(), 0.f);
-        return cand.size() > before;
-    }
-    float share(size_t r, u32 k) const
-    {
-        if (k == refs[r]) return 1.f;
-        const float s = (pair_ms[r][k] / lo - 1.f) / (kSameOverDisjoint - 1.f);
-        return s < 0.f ? 0.f : s > 1.f ? 1.f : s;
-    }
-    void measure_pairs()                         // every (reference, candidate) pair not measured yet
-    {
-        for (size_t r = 0; r < refs.size(); ++r) {
-            pair_ms[r].resize(cand.size(), 0.f);
-            for (u32 k = 0; k < cand.size(); ++k)
-                if (k != refs[r] && pair_ms[r][k] == 0) {
-                    pair_ms[r][k] = probe({refs[r], k});
-                    if (pair_ms[r][k] < lo) lo = pair_ms[r][k];
-                }
-        }
-    }
-    bool add_reference()                         // the candidate the references explain least, if there is one
-    {
-        if (refs.size() >= 4) return false;
-        std::vector<std::pair<float, u32>> unexplained;
-        for (u32 k = 0; k < cand.size(); ++k) {
-            float e = 0;
-            for (size_t r = 0; r < refs.size(); ++r) e = std::max(e, share(r, k));
-            if (e < 0.4f) unexplained.push_back({e, k});
-        }
-        if (unexplained.empty()) return false;
-        std::sort(unexplained.begin(), unexplained.end());
-        u32 pick = unexplained[0].second;
-        for (size_t i = 1; i < unexplained.size() && i < 3; ++i)   // ... preferring a one-sided piece among the three least explained
-            if (alone_ms(unexplained[i].second) > alone_ms(pick)) pick = unexplained[i].second;
-        refs.push_back(pick);
-        pair_ms.emplace_back();
-        return true;
-    }
-    float choose(std::vector<u32>& set)          // n candidates with the smallest largest per-kind sum; returns that kind's share of the set
-    {
-        const size_t R = refs.size();
-        std::vector<float> sums(R + 1, 0.f), sh(R + 1);
-        std::vector<char> taken(cand.size(), 0);
-        set.clear();
-        for (u32 i = 0; i < n; ++i) {
-            int best = -1;
-            float best_max = 0, best_tot = 0;
-            for (u32 k = 0; k < cand.size(); ++k) {
-                if (taken[k]) continue;
-                float rest = 1.f, mx = 0, tot = 0;
-                for (size_t r = 0; r < R; ++r) { const float s = share(r, k); rest -= s; mx = std::max(mx, sums[r] + s); tot += (sums[r] + s) * (sums[r] + s); }
-                if (rest < 0) rest = 0;                              // (kinds no reference stands for)
-                mx = std::max(mx, sums[R] + rest);
-                tot += (sums[R] + rest) * (sums[R] + rest);
-                if (best < 0 || mx < best_max - 1e-3f || (mx < best_max + 1e-3f && tot < best_tot - 1e-3f)) { best = static_cast<int>(k); best_max = mx; best_tot = tot; }
-            }
-            taken[best] = 1;
-            float rest = 1.f;
-            for (size_t r = 0; r < R; ++r) { const float s = share(r, static_cast<u32>(best)); sums[r] += s; rest -= s; }
-            sums[R] += rest < 0 ? 0 : rest;
-            set.push_back(static_cast<u32>(best));
-        }
-        float mx = 0;
-        for (float v : sums) mx = std::max(mx, v);
-        return mx / static_cast<float>(n);
-    }
-    // -> set: the chosen candidates in workspace order; returns the composed probe's ms (0 when there was nothing to choose from)
-    float run(std::vector<u32>& set)
-    {
-        float largest = 1.f;
-        while (cand.size() < max_cand && grow()) {
-            if (cand.size() < n || max_cand <= n) break;
-            if (refs.empty()) {
-                u32 ref = 0;
-                for (u32 k = 0; k < cand.size(); ++k)
-                    if (alone_ms(k) > alone_ms(ref)) ref = k;
-                refs.push_back(ref);
-                pair_ms.emplace_back();
-                lo = 0.94f * alone[ref];                             // (a disjoint pair runs 6-7 % FASTER than a one-sided piece alone; measured pairs refine it)
-            }
-            do measure_pairs(); while (add_reference());
-            largest = choose(set);
-            if (dbg) fprintf(stderr, "[snappier] table workspace: %zu candidate pieces of %.2f GiB, %zu references, disjoint-pair level %.3f ms, largest kind's share of the chosen %u: %.2f\n",
-                             cand.size(), piece_bytes / 1073741824.0, refs.size(), lo, n, largest);
-            if (largest <= 0.36f || (largest <= 0.52f && cand.size() >= 3 * static_cast<size_t>(n))) break;   // three kinds if they turn up within three rounds, else two
-        }
-        if (cand.size() < n) return -1.f;
-        if (set.size() != n) {                                       // no room for spare candidates: the workspace is what could be allocated
-            set.resize(n);
-            for (u32 i = 0; i < n; ++i) set[i] = i;
-            return 0.f;
-        }
-        std::vector<u32> spare;
-        std::vector<char> in_set(cand.size(), 0);
-        for (u32 k : set) in_set[k] = 1;
-        for (u32 k = 0; k < cand.size(); ++k)
-            if (!in_set[k]) spare.push_back(k);
-        float cur = probe(set);
-        const float first_ms = cur;
-        u32 rng = 12345u, accepted = 0;
-        for (u32 t = 0; !spare.empty() && t < 2 * n; ++t) {         // hill climb on the composed probe
-            rng = rng * 1664525u + 1013904223u;
-            const u32 pos = (rng >> 8) % n;
-            rng = rng * 1664525u + 1013904223u;
-            const u32 sp = (rng >> 8) % static_cast<u32>(spare.size());
-            std::swap(set[pos], spare[sp]);
-            const float ms = probe(set);
-            if (ms < cur * 0.996f) { cur = ms; ++accepted; } else std::swap(set[pos], spare[sp]);
-        }
-        if (dbg) fprintf(stderr, "[snappier] table workspace: composed probe %.3f ms, %.3f after a hill climb that kept %u of %u swaps (%u probes in all)\n", first_ms, cur,
-                         accepted, 2 * n, trials);
-        return cur;
-    }
-};
+using snp_piece_search::PieceSearch;   // piece_search.h: why the workspace is made of pieces, and how they are chosen
 
 
 }  // namespace
@@ -486,36 +322,51 @@ struct snp_ctx {
         if (tables.p) (void)hipFree(tables.p);           // (a small workspace of earlier calls: the pieces replace it)
         tables = DevBuf{};
         PieceSearch ps{};
-        ps.stream = stream;
-        ps.nblocks = nblocks;
-        ps.piece_frags = ((nblocks + SNP_TABLE_PIECES_MAX - 1) / SNP_TABLE_PIECES_MAX + 63u) / 64u * 64u;
-        ps.n = (nblocks + ps.piece_frags - 1) / ps.piece_frags;
-        ps.piece_bytes = static_cast<size_t>(ps.piece_frags) * 65536u;
+        const u32 piece_frags = ((nblocks + SNP_TABLE_PIECES_MAX - 1) / SNP_TABLE_PIECES_MAX + 63u) / 64u * 64u;
+        const size_t piece_bytes = static_cast<size_t>(piece_frags) * 65536u;
+        ps.n = (nblocks + piece_frags - 1) / piece_frags;
+        ps.piece_gib = piece_bytes / 1073741824.0;
         ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(table_tries);
         ps.dbg = getenv("SNAPPIER_HIP_DEBUG") != nullptr;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {                // the candidates coexist: stay within half of what is free
             size_t room = free_b / 2;                                        // ... and within the caller's byte cap (SNP_OPT_TABLE_PROBE_MAX_BYTES)
             if (table_probe_max_bytes && table_probe_max_bytes < room) room = static_cast<size_t>(table_probe_max_bytes);
-            if (room / ps.piece_bytes < ps.max_cand) ps.max_cand = room / ps.piece_bytes;
+            if (room / piece_bytes < ps.max_cand) ps.max_cand = room / piece_bytes;
         }
         if (ps.max_cand < ps.n) ps.max_cand = ps.n;                          // the workspace itself is not optional
+        std::vector<u32*> cand;
+        ps.alloc_one = [&]() {
+            void* q = nullptr;
+            if (hipMalloc(&q, piece_bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+            cand.push_back(static_cast<u32*>(q));
+            return true;
+        };
+        ps.probe_set = [&](const std::vector<u32>& pick) {
+            snp_table_pieces t{};
+            for (size_t i = 0; i < pick.size(); ++i) t.p[i] = cand[pick[i]];
+            t.piece_frags = piece_frags;
+            t.n = static_cast<u32>(pick.size());
+            float ms = 1e30f;
+            if (snp_probe_tables(&t, nblocks, 512u, stream, &ms) != hipSuccess) { (void)hipGetLastError(); ms = 1e30f; }
+            return ms;
+        };
         std::vector<u32> set;
         const float ms = ps.run(set);
         if (ms < 0) {
-            for (u32* q : ps.cand) (void)hipFree(q);
+            for (u32* q : cand) (void)hipFree(q);
             err = "hipMalloc(hash tables): out of memory";
             return false;
         }
-        std::vector<char> used(ps.cand.size(), 0);
+        std::vector<char> used(cand.size(), 0);
         tp = snp_table_pieces{};
-        for (u32 i = 0; i < ps.n; ++i) { tp.p[i] = ps.cand[set[i]]; used[set[i]] = 1; piece_mem.push_back(ps.cand[set[i]]); }
-        tp.piece_frags = ps.piece_frags;
+        for (u32 i = 0; i < ps.n; ++i) { tp.p[i] = cand[set[i]]; used[set[i]] = 1; piece_mem.push_back(cand[set[i]]); }
+        tp.piece_frags = piece_frags;
         tp.n = ps.n;
-        for (size_t k = 0; k < ps.cand.size(); ++k)
-            if (!used[k]) (void)hipFree(ps.cand[k]);
+        for (size_t k = 0; k < cand.size(); ++k)
+            if (!used[k]) (void)hipFree(cand[k]);
         counters[2] = static_cast<uint64_t>(ms * 1000.0f);
-        counters[3] = static_cast<uint64_t>(ps.cand.size());
+        counters[3] = static_cast<uint64_t>(cand.size());
         return true;
     }
     bool use_device() { return check(hipSetDevice(device), "hipSetDevice"); }

@@ -1,0 +1,181 @@
+// piece_search.h -- which separately allocated pieces the lane compressor's hash-table workspace is made of.  Plain C++ (no HIP): capi.hip
+// supplies the allocator and the probe; tests/test_piece_search_model.py drives the same code with a model of device memory on the CPU.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <utility>
+#include <vector>
+
+namespace snp_piece_search {
+typedef uint32_t u32;
+
+// ---- where the lane compressor's hash tables live ---------------------------------------------------------------------------------------
+// The kernel is bound by the rate at which HBM serves random 4-byte exchanges spread over the whole 64 KiB-per-fragment workspace, and that
+// rate depends on WHERE the driver placed the memory.  Measured (scripts/microbench_random_table.hip modes m, g and k,
+// profiles/r03y_microbench_*.jsonl): device memory consists of regions of tens of GiB of (at least) three KINDS.  Traffic
+// confined to one kind runs the table walk in 38.0 ms per 4096 probes, spread evenly over two kinds in 31.9 ms, over three in 30.3 ms; the kind
+// is a stable property of where an allocation landed, and one 10 GiB hipMalloc usually lies inside one region (34.5-38.2 ms).  Two 0.6 GiB
+// pieces probed TOGETHER tell whether they share a kind: 4.31-4.36 ms per 512 probes if they do, 3.65-3.68 ms if they do not.
+// So a GiB-sized workspace is built from up to 16 separately allocated pieces, chosen by measurement:
+//   * candidates are allocated 16 at a time; the most one-sided piece of the first round (slowest probed alone) is the first REFERENCE;
+//   * every candidate is probed paired with every reference; share(r, k) = how much of candidate k is of reference r's kind, from where the
+//     pair's time falls between the two levels; a candidate that no reference explains becomes the next reference (up to four);
+//   * the 16 pieces are picked greedily so that the largest per-kind sum stays smallest; candidates keep coming until the largest kind's
+//     share of the set is <= 0.40 (three kinds evenly; <= 0.56, two kinds, from the third round on) or `max_cand` (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, half of free memory, the
+//     byte cap) is reached; a short hill climb on the COMPOSED probe polishes the result.
+// Cost: 0.3-3 s and the candidates' memory, once, at the first large compress call of a context; the losers are freed before it returns.
+struct PieceSearch {
+    u32 n = 0;                                   // pieces the workspace needs
+    size_t max_cand = 0;                         // candidates the search may hold at once
+    double piece_gib = 0;                        // (for the debug lines)
+    bool dbg = false;
+    // The two things the search does to the device, supplied by the caller (capi.hip: hipMalloc / snp_probe_tables; the CPU test: a model):
+    std::function<bool()> alloc_one;                                 // one more candidate; false = out of memory
+    std::function<float(const std::vector<u32>&)> probe_set;         // ms of 512 table-walk probes per fragment on these candidates (folded when fewer than n)
+    size_t ncand = 0;
+    std::vector<float> alone;                    // probed alone (0 = not measured)
+    std::vector<u32> refs;
+    std::vector<std::vector<float>> pair_ms;     // [reference][candidate]
+    float lo = 0;                                // pair level of two pieces that share nothing
+    u32 trials = 0;
+    static constexpr float kSameOverDisjoint = 1.18f;   // 4.33 / 3.67
+
+    float probe(const std::vector<u32>& set)
+    {
+        ++trials;
+        return probe_set(set);
+    }
+    float alone_ms(u32 k)
+    {
+        if (alone[k] == 0) alone[k] = probe({k});
+        return alone[k];
+    }
+    bool grow()
+    {
+        const size_t before = ncand;
+        for (u32 k = 0; k < n && ncand < max_cand; ++k) {
+            if (!alloc_one()) break;
+            ++ncand;
+        }
+        alone.resize(ncand, 0.f);
+        return ncand > before;
+    }
+    float share(size_t r, u32 k) const
+    {
+        if (k == refs[r]) return 1.f;
+        const float s = (pair_ms[r][k] / lo - 1.f) / (kSameOverDisjoint - 1.f);
+        return s < 0.f ? 0.f : s > 1.f ? 1.f : s;
+    }
+    void measure_pairs()                         // every (reference, candidate) pair not measured yet
+    {
+        for (size_t r = 0; r < refs.size(); ++r) {
+            pair_ms[r].resize(ncand, 0.f);
+            for (u32 k = 0; k < ncand; ++k)
+                if (k != refs[r] && pair_ms[r][k] == 0) {
+                    pair_ms[r][k] = probe({refs[r], k});
+                    if (pair_ms[r][k] < lo) lo = pair_ms[r][k];
+                }
+        }
+    }
+    bool add_reference()                         // the candidate the references explain least, if there is one
+    {
+        if (refs.size() >= 4) return false;
+        std::vector<std::pair<float, u32>> unexplained;
+        for (u32 k = 0; k < ncand; ++k) {
+            float e = 0;
+            for (size_t r = 0; r < refs.size(); ++r) e = std::max(e, share(r, k));
+            if (e < 0.4f) unexplained.push_back({e, k});
+        }
+        if (unexplained.empty()) return false;
+        std::sort(unexplained.begin(), unexplained.end());
+        u32 pick = unexplained[0].second;
+        for (size_t i = 1; i < unexplained.size() && i < 3; ++i)   // ... preferring a one-sided piece among the three least explained
+            if (alone_ms(unexplained[i].second) > alone_ms(pick)) pick = unexplained[i].second;
+        refs.push_back(pick);
+        pair_ms.emplace_back();
+        return true;
+    }
+    float choose(std::vector<u32>& set)          // n candidates with the smallest largest per-kind sum; returns that kind's share of the set
+    {
+        const size_t R = refs.size();
+        std::vector<float> sums(R + 1, 0.f), sh(R + 1);
+        std::vector<char> taken(ncand, 0);
+        set.clear();
+        for (u32 i = 0; i < n; ++i) {
+            int best = -1;
+            float best_max = 0, best_tot = 0;
+            for (u32 k = 0; k < ncand; ++k) {
+                if (taken[k]) continue;
+                float rest = 1.f, mx = 0, tot = 0;
+                for (size_t r = 0; r < R; ++r) { const float s = share(r, k); rest -= s; mx = std::max(mx, sums[r] + s); tot += (sums[r] + s) * (sums[r] + s); }
+                if (rest < 0) rest = 0;                              // (kinds no reference stands for)
+                mx = std::max(mx, sums[R] + rest);
+                tot += (sums[R] + rest) * (sums[R] + rest);
+                if (best < 0 || mx < best_max - 1e-3f || (mx < best_max + 1e-3f && tot < best_tot - 1e-3f)) { best = static_cast<int>(k); best_max = mx; best_tot = tot; }
+            }
+            taken[best] = 1;
+            float rest = 1.f;
+            for (size_t r = 0; r < R; ++r) { const float s = share(r, static_cast<u32>(best)); sums[r] += s; rest -= s; }
+            sums[R] += rest < 0 ? 0 : rest;
+            set.push_back(static_cast<u32>(best));
+        }
+        float mx = 0;
+        for (float v : sums) mx = std::max(mx, v);
+        return mx / static_cast<float>(n);
+    }
+    // -> set: the chosen candidates in workspace order; returns the composed probe's ms (0 when there was nothing to choose from)
+    float run(std::vector<u32>& set)
+    {
+        float largest = 1.f;
+        while (ncand < max_cand && grow()) {
+            if (ncand < n || max_cand <= n) break;
+            if (refs.empty()) {
+                u32 ref = 0;
+                for (u32 k = 0; k < ncand; ++k)
+                    if (alone_ms(k) > alone_ms(ref)) ref = k;
+                refs.push_back(ref);
+                pair_ms.emplace_back();
+                lo = 0.94f * alone[ref];                             // (a disjoint pair runs 6-7 % FASTER than a one-sided piece alone; measured pairs refine it)
+            }
+            do measure_pairs(); while (add_reference());
+            largest = choose(set);
+            if (dbg) fprintf(stderr, "[snappier] table workspace: %zu candidate pieces of %.2f GiB, %zu references, disjoint-pair level %.3f ms, largest kind's share of the chosen %u: %.2f\n",
+                             ncand, piece_gib, refs.size(), lo, n, largest);
+            // three kinds if they turn up within three rounds, else two.  (Sixteen pieces over three kinds are 6 + 5 + 5 at best = 0.375; two kinds
+            // balanced read 0.50-0.53 with the noise of the pair probes -- tests/abi/piece_search_model.cpp found the tighter bounds never met.)
+            if (largest <= 0.40f || (largest <= 0.56f && ncand >= 3 * static_cast<size_t>(n))) break;
+        }
+        if (ncand < n) return -1.f;
+        if (set.size() != n) {                                       // no room for spare candidates: the workspace is what could be allocated
+            set.resize(n);
+            for (u32 i = 0; i < n; ++i) set[i] = i;
+            return 0.f;
+        }
+        std::vector<u32> spare;
+        std::vector<char> in_set(ncand, 0);
+        for (u32 k : set) in_set[k] = 1;
+        for (u32 k = 0; k < ncand; ++k)
+            if (!in_set[k]) spare.push_back(k);
+        float cur = probe(set);
+        const float first_ms = cur;
+        u32 rng = 12345u, accepted = 0;
+        for (u32 t = 0; !spare.empty() && t < 2 * n; ++t) {         // hill climb on the composed probe
+            rng = rng * 1664525u + 1013904223u;
+            const u32 pos = (rng >> 8) % n;
+            rng = rng * 1664525u + 1013904223u;
+            const u32 sp = (rng >> 8) % static_cast<u32>(spare.size());
+            std::swap(set[pos], spare[sp]);
+            const float ms = probe(set);
+            if (ms < cur * 0.996f) { cur = ms; ++accepted; } else std::swap(set[pos], spare[sp]);
+        }
+        if (dbg) fprintf(stderr, "[snappier] table workspace: composed probe %.3f ms, %.3f after a hill climb that kept %u of %u swaps (%u probes in all)\n", first_ms, cur,
+                         accepted, 2 * n, trials);
+        return cur;
+    }
+};
+
+}  // namespace snp_piece_search
