@@ -25,9 +25,12 @@ typedef uint32_t u32;
 //   * every candidate is probed paired with every reference; share(r, k) = how much of candidate k is of reference r's kind, from where the
 //     pair's time falls between the two levels; a candidate that no reference explains becomes the next reference (up to four);
 //   * the 16 pieces are picked greedily so that the largest per-kind sum stays smallest; candidates keep coming until the largest kind's
-//     share of the set is <= 0.40 (three kinds evenly; <= 0.56, two kinds, from the third round on) or `max_cand` (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, half of free memory, the
-//     byte cap) is reached; a short hill climb on the COMPOSED probe polishes the result.
-// Cost: 0.3-3 s and the candidates' memory, once, at the first large compress call of a context; the losers are freed before it returns.
+//     share of the set is <= 0.40 (three kinds evenly; <= 0.56, two kinds, from the third round on) or `max_cand`
+//     (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, half of free memory, the byte cap) is reached; a short hill climb on the COMPOSED
+//     probe polishes the result.
+// Cost: typically 0.5 s and three workspaces' worth of candidate memory (up to a few seconds and `max_cand` pieces when one kind is all
+// there is for a long while), once, at the first large compress call of a context or in snp_ctx_reserve_compress; the losers are freed
+// before it returns.
 struct PieceSearch {
     u32 n = 0;                                   // pieces the workspace needs
     size_t max_cand = 0;                         // candidates the search may hold at once
@@ -102,7 +105,7 @@ struct PieceSearch {
     float choose(std::vector<u32>& set)          // n candidates with the smallest largest per-kind sum; returns that kind's share of the set
     {
         const size_t R = refs.size();
-        std::vector<float> sums(R + 1, 0.f), sh(R + 1);
+        std::vector<float> sums(R + 1, 0.f);                     // per reference's kind, + one for whatever no reference stands for
         std::vector<char> taken(ncand, 0);
         set.clear();
         for (u32 i = 0; i < n; ++i) {
