@@ -584,15 +584,15 @@ emit_remainder:
 }  // namespace
 
 // ---- workspace placement probe ---------------------------------------------------------------------------------
-// The kernel is bound by the rate at which HBM serves random 4-byte read-modify-writes spread over the whole table
-// workspace, and that rate depends on WHERE the driver placed the buffer: the same code measures 25-33 ms per 671 M
-// probes on differently placed 10 GiB buffers (four discrete levels; reads alone do not vary).  So when
-// a large workspace is allocated, capi.hip allocates a few candidates, times this probe (the table traffic of the
-// compressor and nothing else, a few ms) on each and keeps the fastest.
-// Round 3: the probe issues atomic EXCHANGES, as the kernel now does.  With load + store pairs it saw two levels (5.6 / 6.25 ms) and the
-// kernel still ran anywhere between 110.4 and 117.7 ms on "fast" candidates; with exchanges it sees more (5.75-6.06 / 6.44-6.59 /
-// 7.09-7.26 ms: about one candidate in twelve is in the first group) and a candidate of the first group runs the kernel in 101-104 ms
-// instead of 110-113 (profiles/r03y_table_placement_runs*.txt).
+// The kernel is bound by the rate at which HBM serves random 4-byte exchanges spread over the whole table workspace, and that rate
+// depends on WHERE the driver placed the memory (regions of three kinds; the traffic wants to be spread over them: piece_search.h,
+// DESIGN.md 4.3).  This probe is the measuring instrument of the search that picks the workspace's pieces (capi.hip, ensure_tables):
+// the table traffic of the compressor and nothing else -- every lane walks a chain of dependent exchanges through its own 64 KiB table --
+// on a SET of candidate pieces.  A set smaller than the workspace is probed folded (several lanes per table), so that one or two
+// pieces see the whole grid's concurrency: one 0.6 GiB piece alone 3.4-3.6 ms per 512 probes when it straddles kinds, 3.9 when it does
+// not; two pieces 3.65-3.68 ms when they are of different kinds, 4.31-4.36 when of the same; sixteen pieces 3.8 / 4.0 / 4.75 ms spread over
+// three / two / one kind.  (History: rounds 1-2 probed whole 10 GiB candidates with load + store pairs and saw two levels; with exchanges,
+// four -- the shares 1, 3/4, 1/2 ... of one kind inside one contiguous allocation.)
 namespace {
 __global__ __launch_bounds__(SNP_WAVE) void k_probe_tables(const snp_table_pieces tp, u32 nblocks, u32 probes)
 {
