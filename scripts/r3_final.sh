@@ -12,7 +12,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$
 f=$(find gpurun_out/${T}_prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${T}_bench_kernel_stats.csv; head -6 gpurun_out/${T}_bench_kernel_stats.csv | cut -c1-200
 timeout 600 python scripts/bench_configs.py 2>&1 | grep "config" > gpurun_out/${T}_other_configs.jsonl; cat gpurun_out/${T}_other_configs.jsonl | cut -c1-400
 timeout 600 python bench.py --config5-lines --no-cpu-baseline --steps 3 > gpurun_out/${T}_bench_config5_lines.json 2>/dev/null; tail -c 900 gpurun_out/${T}_bench_config5_lines.json
-timeout 300 python scripts/small_blocks.py 64 128 256 512 1024 4096 16384 65536 2>&1 | grep block_bytes > gpurun_out/${T}_small_blocks.jsonl; cat gpurun_out/${T}_small_blocks.jsonl
+timeout 300 python scripts/small_blocks.py 64 96 128 192 256 384 512 768 1024 4096 16384 65536 2>&1 | grep block_bytes > gpurun_out/${T}_small_blocks.jsonl; cat gpurun_out/${T}_small_blocks.jsonl
 timeout 600 python scripts/host_api_rates.py 65536 1048576 4194304 16777216 268435456 1073741824 2>&1 | grep bytes > gpurun_out/${T}_host_api.jsonl; cat gpurun_out/${T}_host_api.jsonl
 for nbk in 1024 4096 8192 16383 16384 32768 65536; do timeout 200 python scripts/time_compress.py $nbk 2>&1 | tail -1; done > gpurun_out/${T}_compress_by_batch.jsonl; cat gpurun_out/${T}_compress_by_batch.jsonl
 for d in html low mixed; do for m in queued chains; do DATA=$d SNAPPIER_HIP_DECODE=$m timeout 300 python scripts/time_decompress.py 163840 2>&1 | tail -1; done; done > gpurun_out/${T}_decode_front_ends.jsonl; cat gpurun_out/${T}_decode_front_ends.jsonl
