@@ -24,7 +24,8 @@ def _stale(target: str, sources: list[str]) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    deps = sources + [os.path.join(CSRC, "snp_device.h"), os.path.join(HERE, "..", "include", "snappier_hip.h")]
+    inc = os.path.join(HERE, "..", "include")
+    deps = sources + [os.path.join(d, f) for d in (CSRC, inc) for f in os.listdir(d) if f.endswith(".h")]   # every header either directory holds
     return any(os.path.getmtime(s) > t for s in deps)
 
 

@@ -25,10 +25,10 @@ typedef uint32_t u32;
 //   * every candidate is probed paired with every reference; share(r, k) = how much of candidate k is of reference r's kind, from where the
 //     pair's time falls between the two levels; a candidate that no reference explains becomes the next reference (up to four);
 //   * the 16 pieces are picked greedily so that the largest per-kind sum stays smallest; candidates keep coming until the largest kind's
-//     share of the set is <= 0.40 (three kinds evenly; <= 0.56, two kinds, from the third round on) or `max_cand`
+//     share of the set is <= 0.40 (three kinds evenly; <= 0.56, two kinds, from the sixth round on) or `max_cand`
 //     (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, half of free memory, the byte cap) is reached; a short hill climb on the COMPOSED
 //     probe polishes the result.
-// Cost: typically 0.5 s and three workspaces' worth of candidate memory (up to a few seconds and `max_cand` pieces when one kind is all
+// Cost: typically 0.5-1.2 s and three to six workspaces' worth of candidate memory (up to a few seconds and `max_cand` pieces when one kind is all
 // there is for a long while), once, at the first large compress call of a context or in snp_ctx_reserve_compress; the losers are freed
 // before it returns.
 struct PieceSearch {
@@ -46,6 +46,7 @@ struct PieceSearch {
     float lo = 0;                                // pair level of two pieces that share nothing
     u32 trials = 0;
     static constexpr float kSameOverDisjoint = 1.18f;   // 4.33 / 3.67
+    static constexpr size_t kPatience = 6;              // rounds of n candidates spent looking for a THIRD kind once two are balanced (three kinds: 30.3 ms per 4096 probes, two: 31.9)
 
     float probe(const std::vector<u32>& set)
     {
@@ -148,9 +149,9 @@ struct PieceSearch {
             largest = choose(set);
             if (dbg) fprintf(stderr, "[snappier] table workspace: %zu candidate pieces of %.2f GiB, %zu references, disjoint-pair level %.3f ms, largest kind's share of the chosen %u: %.2f\n",
                              ncand, piece_gib, refs.size(), lo, n, largest);
-            // three kinds if they turn up within three rounds, else two.  (Sixteen pieces over three kinds are 6 + 5 + 5 at best = 0.375; two kinds
+            // three kinds if they turn up within kPatience rounds, else two.  (Sixteen pieces over three kinds are 6 + 5 + 5 at best = 0.375; two kinds
             // balanced read 0.50-0.53 with the noise of the pair probes -- tests/abi/piece_search_model.cpp found the tighter bounds never met.)
-            if (largest <= 0.40f || (largest <= 0.56f && ncand >= 3 * static_cast<size_t>(n))) break;
+            if (largest <= 0.40f || (largest <= 0.56f && ncand >= kPatience * static_cast<size_t>(n))) break;
         }
         if (ncand < n) return -1.f;
         if (set.size() != n) {                                       // no room for spare candidates: the workspace is what could be allocated

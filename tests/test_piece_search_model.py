@@ -37,9 +37,9 @@ def test_three_kinds_are_used_when_they_turn_up_early(scenarios):
     assert r["references"] == 3 and r["largest_share"] <= 0.40 and r["candidates"] <= 48
 
 
-def test_two_kinds_stop_the_search_after_three_rounds(scenarios):
+def test_two_kinds_stop_the_search_after_six_rounds(scenarios):
     r = scenarios["two kinds early"]
-    assert r["largest_share"] <= 0.56 and r["candidates"] == 48
+    assert r["largest_share"] <= 0.56 and r["candidates"] == 96
 
 
 def test_the_search_goes_on_while_it_has_seen_one_kind_only(scenarios):
