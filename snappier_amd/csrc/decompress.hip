@@ -237,7 +237,8 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #endif
 #ifndef SNP_D_ABLATE
 #define SNP_D_ABLATE 0      // TIMING-ONLY ablations of the sub-chain front end (the output is wrong): 1 no first-pass copies, 2 no serial finish,
-#endif                      // 4 no write-out, 16 no second pass, 32 tag lists only (no batches), 64 first-pass copy sources pulled to within 1 KiB (no far reads)
+#endif                      // 4 no write-out, 16 no second pass, 32 tag lists only (no batches), 64 first-pass copy sources pulled to within 1 KiB (no far reads),
+                            // 128 one 16-byte piece per tag in the first pass whatever its length (10.95 -> 9.70 ms: what the 18 % of tags longer than 16 bytes cost)
 #ifndef SNP_D_PASS2
 #define SNP_D_PASS2 1       // sub-chain front end: second lane-parallel pass over the tags pass 1 could not take (0: they all finish one by one)
 #endif
@@ -1040,7 +1041,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             const u32 s_lo = ostart - off;
             // (timing-only ablation 64: every copy source pulled to within 1 KiB below the batch -- what if far back-references cost nothing?
             //  10.9 vs 11.2 ms, profiles/r03b_decode_far_source_ablation.jsonl: they nearly do already)
-            if (ready && !(SNP_D_ABLATE & 1)) lane_copy2(my, is_lit ? src + wbase + body : dst + ((SNP_D_ABLATE & 64) ? max(s_lo, max(mark, 1024u) - 1024u) : s_lo), len);
+            if (ready && !(SNP_D_ABLATE & 1)) lane_copy2(my, is_lit ? src + wbase + body : dst + ((SNP_D_ABLATE & 64) ? max(s_lo, max(mark, 1024u) - 1024u) : s_lo), (SNP_D_ABLATE & 128) ? min(len, 16u) : len);   // (ablation 128: one 16-byte piece per tag, whatever its length)
             u64 pend = ballot64(act && !ready);
             DPROF_ADD(0, 1);
             DPROF_ADD(1, ne);
