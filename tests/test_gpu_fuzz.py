@@ -388,7 +388,13 @@ def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
             if name == "capped":
                 cd.ctx.set_option(N.OPT_TABLE_PROBE_MAX_BYTES, 1 << 30)
             cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, 2)
+            if name == "searched" and nb == 20001:                     # snp_ctx_reserve_compress: the search runs now, the call below finds the workspace built
+                cd.ctx.reserve_compress(nb)
+                searched_at_reserve = cd.ctx.counter(3)
+                assert searched_at_reserve >= 32 and cd.ctx.counter(2) > 0
             out, out_off, out_len, st = cd.compress(raw, off, lens)
+            if name == "searched" and nb == 20001:
+                assert cd.ctx.counter(3) == searched_at_reserve, "the compress call searched again after snp_ctx_reserve_compress"
             torch.cuda.synchronize()
             assert int((st != 0).sum()) == 0
             crcs = cd.crc32c(out, out_off, out_len)
