@@ -253,6 +253,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     if (b >= nblocks) return;
     const bool staged = (lit_blind & 16) != 0;
     const bool t_swap = kSlots == 1 && (lit_blind & 64) != 0;          // probe + insert as one atomic exchange (one probe per trip only)
+    bool in_win = (lit_blind & 128) != 0;                              // 16-byte register window over the input for the probe bytes (n >= 32, set below)
     OutStage stg{(SMALL ? s_dyn + blockDim.x * (small_max + 16u) : s_out) + threadIdx.x * kStageStride, 0};
 
     LaneCtx c;
@@ -294,6 +295,9 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     enum : u32 { kScan = 0, kPost = 1, kExtend = 2, kDone = 3 };
     u32 mode = kDone;
     u32 next_emit = 0, skip = 32, cand = 0, base = 0, mlen = 0, limit = 0;
+    snp_u128_unaligned win = {};                                       // option bit 7: input bytes [win_at, win_at + 16)
+    u32 win_at = 0x80000000u;
+    in_win = in_win && n >= 32;
     if (n >= 15) {                                                     // :190
         const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << (31u - __clz(n - 1)));   // HashTable.cs:57-71
         c.mask = 2 * (tsize - 1);                                      // :181
@@ -335,7 +339,25 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 legal[k] = ok;
                 q = nx[k];
             }
-            w0 = ld64u(c.src + ip - (post ? 1u : 0u));                  // ip <= limit = n - 15: in bounds
+            const u32 at = ip - (post ? 1u : 0u);                       // ip <= limit = n - 15: in bounds
+            if (in_win) {
+                // the 8 probe bytes come out of a 16-byte register window that is reloaded when the scan leaves it: a stride-1 scan
+                // asks memory for input once per 9 probes instead of once per probe
+                u32 o = at - win_at;
+                if (o > 8u) {
+                    win_at = min(at, n - 16u);                          // at <= limit = n - 15: the window is pulled back inside the fragment
+                    win = *reinterpret_cast<const snp_u128_unaligned*>(c.src + win_at);
+                    o = at - win_at;                                    // 0 or 1
+                }
+                const u32 dq = o >> 2, sh = (o & 3u) * 8u;
+                const u32 a0 = dq == 0 ? win.v[0] : dq == 1 ? win.v[1] : win.v[2];
+                const u32 a1 = dq == 0 ? win.v[1] : dq == 1 ? win.v[2] : win.v[3];
+                const u32 a2 = dq == 0 ? win.v[2] : dq == 1 ? win.v[3] : 0u;
+                const u64 lo = (static_cast<u64>(a1) << 32) | a0;
+                w0 = sh ? (lo >> sh) | (static_cast<u64>(a2) << (64u - sh)) : lo;
+            } else {
+                w0 = ld64u(c.src + at);
+            }
         } else {
 #pragma unroll
             for (u32 k = 0; k < kSlots; ++k) { p[k] = nx[k] = sk[k] = 0; legal[k] = false; }
@@ -674,12 +696,15 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // Output-store options (bit 0: a short literal may overshoot with one 16-byte store, bit 1: tag + body of a literal in
     // one store, bit 2: a copy tag as one 4-byte store, bit 3: 16- instead of 32-byte extension trips, bit 4: output staged
     // in LDS and written as whole 64-byte runs, bit 6: probe + insert as one atomic exchange (table_swap, one-probe-per-trip launches); default
-    // 1+2+4+16+64).  SNAPPIER_HIP_EXACT_LITERALS=1 = none (exact-length stores only);
+    // 1+2+4+16+64; + bit 7 from 131 072 fragments: the probe bytes out of a 16-byte register window over the input, reloaded when the scan leaves
+    // it -- one input load per ~9 probes.  On a one-allocation workspace that measured -0.3 % and was removed; on the piece workspace, where
+    // the tables are no longer the only thing the memory system is busy with, same-process A/B: html 99.45 -> 97.29 ms, mixed 146.0 -> 144.6,
+    // low entropy 35.75 -> 35.58; mid-size batches lose 1-2 % and do not get it).  SNAPPIER_HIP_EXACT_LITERALS=1 = none (exact-length stores only);
     // SNAPPIER_HIP_CL_OPTS=<mask> picks a subset -- read per launch, so one process can A/B on the same workspace.
     const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");
     const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
     // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
-    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 127) : ((nblocks >= 32768 ? 23 : 7) | 64);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
+    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0));   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
