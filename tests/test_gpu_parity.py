@@ -375,7 +375,7 @@ def test_decompress_batch_per_block_status(codec):
     assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
 
 
-@pytest.mark.parametrize("layout", ["win", "win-np2", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31"])
+@pytest.mark.parametrize("layout", ["win", "win-np2", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31", "lanes-opts87-slots1", "lanes-opts215-slots1", "lanes-opts151-slots2"])
 def test_compress_layouts_are_bit_identical(layout, monkeypatch):
     """Both compressor layouts (one fragment per wavefront with the table in LDS -- the window kernel; one fragment per lane with the table
     in an HBM workspace) must give the oracle's bytes on every kind of input, ragged lengths included."""
@@ -384,8 +384,10 @@ def test_compress_layouts_are_bit_identical(layout, monkeypatch):
         monkeypatch.setenv("SNAPPIER_HIP_WIN_NP", "2")
     if layout.endswith("-exact"):       # short literals stored with exact-length stores instead of one 16-byte store
         monkeypatch.setenv("SNAPPIER_HIP_EXACT_LITERALS", "1")
-    if "-opts" in layout:               # lane kernel with another set of output-store options (default 23; 7 = no LDS staging)
-        monkeypatch.setenv("SNAPPIER_HIP_CL_OPTS", layout.split("-opts")[1])
+    if "-opts" in layout:               # lane kernel with another set of options (7 = no LDS staging; + 64 probe + insert as one atomic exchange,
+        monkeypatch.setenv("SNAPPIER_HIP_CL_OPTS", layout.split("-opts")[1].split("-")[0])   # + 128 input register window: what >= 131 072-fragment launches run)
+    if "-slots" in layout:              # probes per trip (the exchange acts with one only; batches this small default to two)
+        monkeypatch.setenv("SNAPPIER_HIP_CL_SLOTS", layout.split("-slots")[1])
     html = read_testdata("html")
     for variant in VARIANTS:
         cd = SB.BlockCodec(0, variant)
