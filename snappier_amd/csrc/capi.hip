@@ -365,7 +365,7 @@ struct snp_ctx {
         tp.n = ps.n;
         for (size_t k = 0; k < cand.size(); ++k)
             if (!used[k]) (void)hipFree(cand[k]);
-        counters[2] = static_cast<uint64_t>(ms * 1000.0f);
+        counters[2] = ms < 1e6f ? static_cast<uint64_t>(ms * 1000.0f) : 0;    // (a probe that failed reports 1e30: the set then is whatever the arithmetic picked)
         counters[3] = static_cast<uint64_t>(cand.size());
         return true;
     }
