@@ -15,6 +15,7 @@ using snp_piece_search::PieceSearch;
 typedef std::array<float, 3> Shares;
 
 static uint32_t g_rng = 1;
+static float g_contrast = 1.0f;   // scales the kind-dependent part of every probe: a batch size at which one kind and two kinds are closer together
 static float noise() { g_rng = g_rng * 1664525u + 1013904223u; return 1.0f + (static_cast<float>(g_rng >> 8) / 16777216.0f - 0.5f) * 0.006f; }
 
 struct Memory {
@@ -32,7 +33,7 @@ struct Memory {
     {
         const float m = largest(set);
         const float a = set.size() == 2 ? 3.01f : 3.23f, b = set.size() == 1 ? 0.70f : set.size() == 2 ? 1.32f : 1.52f;
-        return (a + b * m) * noise();
+        return (a + b * g_contrast * (m - 0.5f) + b * 0.5f) * noise();   // (contrast 1: a + b x m; the balanced level stays where it is)
     }
 };
 
@@ -82,6 +83,10 @@ int main()
     scenario("second kind after 110 candidates", runs({{0, 110}, {-1, 1}, {1, 100}}), 212);
     // one kind only, as far as the search may go
     scenario("one kind only", runs({{0, 300}}), 64);
+    // another batch size: one kind and two kinds only 10 % apart instead of 18 %
+    g_contrast = 0.55f;
+    scenario("two kinds early, weak contrast", runs({{0, 20}, {-1, 1}, {1, 120}, {2, 100}}), 256);
+    g_contrast = 1.0f;
     // everything straddles (balanced pieces alone)
     scenario("all pieces balanced", runs({{0, 1}, {-1, 60}, {1, 1}}), 256);
     // no room for spare candidates: the workspace is what could be allocated
