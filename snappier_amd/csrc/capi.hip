@@ -296,7 +296,7 @@ struct snp_ctx {
         piece_mem.clear();
         tp = snp_table_pieces{};
     }
-    bool ensure_tables(u32 nblocks)
+    bool ensure_tables(u32 nblocks, bool thorough = false)
     {
         const size_t bytes = snp_compress_lanes_workspace(nblocks);
         if (!piece_mem.empty()) {
@@ -328,6 +328,7 @@ struct snp_ctx {
         ps.piece_gib = piece_bytes / 1073741824.0;
         ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(table_tries);
         ps.dbg = getenv("SNAPPIER_HIP_DEBUG") != nullptr;
+        if (thorough) ps.patience = 64;                                       // snp_ctx_reserve_compress: the caller has time -- look for a third kind as far as max_cand allows
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {                // the candidates coexist: stay within half of what is free
             size_t room = free_b / 2;                                        // ... and within the caller's byte cap (SNP_OPT_TABLE_PROBE_MAX_BYTES)
@@ -511,7 +512,7 @@ snp_status snp_ctx_reserve_compress(snp_ctx* c, uint32_t nfragments)
     if (nfragments == 0) return SNP_OK;
     DevGuard dg(c);
     if (!dg.ok) return SNP_ERR_DEVICE;
-    return c->ensure_tables(nfragments < c->slice_fragments ? nfragments : c->slice_fragments) ? SNP_OK : SNP_ERR_DEVICE;
+    return c->ensure_tables(nfragments < c->slice_fragments ? nfragments : c->slice_fragments, true) ? SNP_OK : SNP_ERR_DEVICE;
 }
 
 snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)

@@ -25,7 +25,7 @@ typedef uint32_t u32;
 //   * every candidate is probed paired with every reference; share(r, k) = how much of candidate k is of reference r's kind, from where the
 //     pair's time falls between the two levels; a candidate that no reference explains becomes the next reference (up to four);
 //   * the 16 pieces are picked greedily so that the largest per-kind sum stays smallest; candidates keep coming until the largest kind's
-//     share of the set is <= 0.40 (three kinds evenly; <= 0.56, two kinds, from the sixth round on) or `max_cand`
+//     share of the set is <= 0.40-0.47 with three references (three kinds about evenly; <= 0.56, two kinds, from round `patience` on) or `max_cand`
 //     (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, half of free memory, the byte cap) is reached; a short hill climb on the COMPOSED
 //     probe polishes the result.
 // Cost: typically 0.5-1.2 s and three to six workspaces' worth of candidate memory (up to a few seconds and `max_cand` pieces when one kind is all
@@ -46,7 +46,8 @@ struct PieceSearch {
     float lo = 0;                                // pair level of two pieces that share nothing
     u32 trials = 0;
     static constexpr float kSameOverDisjoint = 1.18f;   // 4.33 / 3.67
-    static constexpr size_t kPatience = 6;              // rounds of n candidates spent looking for a THIRD kind once two are balanced (three kinds: 30.3 ms per 4096 probes, two: 31.9)
+    size_t patience = 6;                                // rounds of n candidates spent looking for a THIRD kind once two are balanced (three kinds: 30.3 ms per 4096 probes, two: 31.9;
+                                                        // snp_ctx_reserve_compress, which runs when the caller has time, raises it to whatever max_cand allows)
 
     float probe(const std::vector<u32>& set)
     {
@@ -149,9 +150,14 @@ struct PieceSearch {
             largest = choose(set);
             if (dbg) fprintf(stderr, "[snappier] table workspace: %zu candidate pieces of %.2f GiB, %zu references, disjoint-pair level %.3f ms, largest kind's share of the chosen %u: %.2f\n",
                              ncand, piece_gib, refs.size(), lo, n, largest);
-            // three kinds if they turn up within kPatience rounds, else two.  (Sixteen pieces over three kinds are 6 + 5 + 5 at best = 0.375; two kinds
-            // balanced read 0.50-0.53 with the noise of the pair probes -- tests/abi/piece_search_model.cpp found the tighter bounds never met.)
-            if (largest <= 0.40f || (largest <= 0.56f && ncand >= kPatience * static_cast<size_t>(n))) break;
+            // Three kinds if they turn up within `patience` rounds, else two.  (Sixteen pieces over three kinds are 6 + 5 + 5 at best = 0.375, and the
+            // third kind's pieces are usually few: the estimate then stays at 0.41-0.46 however many more candidates come -- composed probe
+            // 3.78-3.80 ms either way; two kinds balanced read 0.50-0.53 through the noise of the pair probes.  tests/abi/piece_search_model.cpp
+            // found the first, tighter bounds never met; a run on the GPU found "0.39" with TWO references -- the share no reference explains
+            // posing as a third kind -- hence the count of references in the rule.)
+            const bool three = refs.size() >= 3;
+            if (three && (largest <= 0.40f || (largest <= 0.47f && ncand >= 3 * static_cast<size_t>(n)))) break;
+            if (largest <= 0.56f && ncand >= patience * static_cast<size_t>(n)) break;
         }
         if (ncand < n) return -1.f;
         if (set.size() != n) {                                       // no room for spare candidates: the workspace is what could be allocated

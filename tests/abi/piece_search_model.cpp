@@ -50,7 +50,7 @@ static std::vector<Shares> runs(const std::vector<std::pair<int, int>>& spec)   
     return v;
 }
 
-static void scenario(const char* name, const std::vector<Shares>& layout, size_t max_cand, size_t fail_after = ~size_t(0))
+static void scenario(const char* name, const std::vector<Shares>& layout, size_t max_cand, size_t fail_after = ~size_t(0), size_t patience = 0)
 {
     Memory mem{layout, fail_after, {}};
     PieceSearch ps{};
@@ -58,6 +58,7 @@ static void scenario(const char* name, const std::vector<Shares>& layout, size_t
     ps.max_cand = max_cand;
     ps.piece_gib = 0.625;
     ps.dbg = getenv("SNAPPIER_HIP_DEBUG") != nullptr;
+    if (patience) ps.patience = patience;
     ps.alloc_one = [&]() { return mem.alloc(); };
     ps.probe_set = [&](const std::vector<uint32_t>& set) { return mem.probe(set); };
     std::vector<uint32_t> set;
@@ -79,6 +80,8 @@ int main()
     scenario("three kinds early", runs({{0, 2}, {-1, 1}, {1, 9}, {-1, 2}, {2, 14}, {-1, 1}, {0, 30}, {1, 200}}), 256);
     // two kinds within the first rounds, the third far away
     scenario("two kinds early", runs({{0, 20}, {-1, 1}, {1, 120}, {2, 100}}), 256);
+    // ... the same memory searched by snp_ctx_reserve_compress (the caller has time: patience as far as max_cand allows): the third kind is found
+    scenario("two kinds early, thorough", runs({{0, 20}, {-1, 1}, {1, 120}, {2, 100}}), 256, ~size_t(0), 64);
     // a process whose first hundred candidates are of one kind (seen once: profiles/r03y_piece_search_compress.txt)
     scenario("second kind after 110 candidates", runs({{0, 110}, {-1, 1}, {1, 100}}), 212);
     // one kind only, as far as the search may go

@@ -24,7 +24,7 @@ def scenarios(tmp_path_factory):
 
 
 def test_every_scenario_ran_and_picks_sixteen_distinct_candidates(scenarios):
-    assert len(scenarios) == 9
+    assert len(scenarios) == 10
     for name, r in scenarios.items():
         assert r["distinct"] and r["in_range"], name
         if name != "out of memory at 10":
@@ -40,6 +40,11 @@ def test_three_kinds_are_used_when_they_turn_up_early(scenarios):
 def test_two_kinds_stop_the_search_after_six_rounds(scenarios):
     r = scenarios["two kinds early"]
     assert r["largest_share"] <= 0.56 and r["candidates"] == 96
+
+
+def test_a_thorough_search_goes_on_to_the_third_kind(scenarios):
+    r = scenarios["two kinds early, thorough"]
+    assert r["references"] == 3 and r["largest_share"] <= 0.45 and 144 <= r["candidates"] <= 192
 
 
 def test_weaker_contrast_between_the_levels_still_ends_balanced(scenarios):
