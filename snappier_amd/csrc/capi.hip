@@ -71,10 +71,9 @@ struct snp_ctx {
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
     int dec_lds = 0;         // dynamic LDS bytes per decode wavefront (occupancy throttle)
     int decode_layout = 0;   // 0 default (small blocks one per lane, the rest one per wavefront), 1 a debug front end is pinned
-    int table_tries = 16;    // candidates tried when a >= 1 GiB hash-table workspace is allocated (SNAPPIER_HIP_TABLE_TRIES / SNP_OPT_TABLE_PROBE_TRIES; as many of
-                             // them as fit in half of the free memory and under the byte cap: 13 for the 10.7 GB of the headline batch).  Round 3: about one
-                             // allocation in twelve lands on the fastest of the levels the exchange probe sees (kernel 101-104 ms instead of 110-113):
-                             // thirteen candidates find one two times in three, profiles/r03y_table_placement_runs_exchange_probe.txt
+    int table_tries = 16;    // workspaces' worth of candidate pieces the search for a >= 1 GiB hash-table workspace may hold at once (SNAPPIER_HIP_TABLE_TRIES /
+                             // SNP_OPT_TABLE_PROBE_TRIES; never more than fit in half of the free memory and under the byte cap; 1 = no search, one allocation).
+                             // The search stops long before that when it can: piece_search.h
     uint64_t table_probe_max_bytes = 0;   // SNP_OPT_TABLE_PROBE_MAX_BYTES: cap on what the placement probe's candidates may occupy together (0 = half of free memory only)
     u32 par_min = 4 * SNP_BLOCK_SIZE;   // single blocks at least this long are decoded one wavefront per 64 KiB fragment (0 = never)
     int compress_mode = 0;   // 0 auto by batch size, 2 fragment-per-lane with HBM tables (compress_lanes.hip), 3 fragment-per-wavefront
