@@ -427,6 +427,7 @@ def main():
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
                        "layout": "decompress: one block per wavefront (sub-chain tag parse over 2 KiB super-windows, 64 tags per execution batch staged in LDS); compress: one fragment per lane, hash tables in an HBM workspace of 16 pieces spread over the kinds of device memory, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
+                       "workspace": "hash-table workspace built by snp_ctx_reserve_compress before the buffers are allocated (a service's start-up; untimed, like the setup pass)" if not os.environ.get("BENCH_NO_RESERVE") else "hash-table workspace built by the untimed setup pass",
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,
