@@ -287,11 +287,22 @@ def decompress_batch(inp: np.ndarray, in_off: np.ndarray, in_len: np.ndarray, ou
     return out, out_len, status
 
 
-def crc32c_batch(inp: np.ndarray, in_off: np.ndarray, in_len: np.ndarray, masked: bool = False):
+def crc32c_batch(inp: np.ndarray, in_off: np.ndarray, in_len: np.ndarray, masked: bool = False, threads: int = 1):
     nb = len(in_len)
     out = np.zeros(nb, dtype=np.uint32)
     inp = np.ascontiguousarray(inp, dtype=np.uint8)
     in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
     in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
-    lib().orc_crc32c_batch(inp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, 0, nb, int(masked), out.ctypes.data)
+    L = lib()
+
+    def run(r):
+        L.orc_crc32c_batch(inp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, r[0], r[1], int(masked), out.ctypes.data)
+
+    ranges = _stripe(nb, threads)
+    if len(ranges) <= 1:
+        for r in ranges:
+            run(r)
+    else:
+        with ThreadPoolExecutor(len(ranges)) as ex:
+            list(ex.map(run, ranges))
     return out

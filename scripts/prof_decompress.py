@@ -35,7 +35,11 @@ if mode == "chains":
              "A + overrun trips (wave max)", "chains walked on by the wave", "tags of those walks", "lanes on the true chain"]
     for k, nme in enumerate(names):
         print(f"chains: {nme:34s} {buf[k]/nb:12.1f} per block")
-tn = ["stage input", "chains, merge, tag list", "batch top wait + decode + scan + checks", "first pass (loads, stage stores)", "second pass + in-order finish", "write-out + store acknowledgement"] if mode == "chains" else ["wait input window", "parse (decode, chain, scan, enqueue)", "first pass", "extra pass", "serial finish"] if mode == "queued" else \
+if mode == "ring":
+    names = ["batches", "tags in batches", "super-windows", "doubling rounds", "sub-steps with an in-step source", "far tags"]
+    for k, nme in enumerate(names):
+        print(f"ring: {nme:34s} {buf[k]/nb:12.1f} per block")
+tn = ["stage input", "chains, merge, tag list", "batch top: tag bytes, decode, scan, checks", "far pieces, marks, recs", "sub-steps", "write-out"] if mode == "ring" else ["stage input", "chains, merge, tag list", "batch top wait + decode + scan + checks", "first pass (loads, stage stores)", "second pass + in-order finish", "write-out + store acknowledgement"] if mode == "chains" else ["wait input window", "parse (decode, chain, scan, enqueue)", "first pass", "extra pass", "serial finish"] if mode == "queued" else \
      ["wait input window", "tag decode + next ptrs", "chain walk", "prefix sum + checks", "copies (all rounds)"]
 tot = sum(buf[10:16])
 for k, nme in enumerate(tn):

@@ -466,7 +466,8 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     const char* m = getenv("SNAPPIER_HIP_DECODE");
     if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
     if (m && strcmp(m, "batched") == 0) c->fenced |= 4;                 // token-parallel batches without the execution queue
-    if (!m || strcmp(m, "chains") == 0 || (strcmp(m, "queued") != 0 && strcmp(m, "serial") != 0 && strcmp(m, "batched") != 0))
+    if (m && strcmp(m, "ring") == 0) c->fenced |= 8 | 32;              // sub-chain parse + output-granular execution through an LDS ring (FRONT = 4)
+    else if (!m || strcmp(m, "chains") == 0 || (strcmp(m, "queued") != 0 && strcmp(m, "serial") != 0 && strcmp(m, "batched") != 0))
         c->fenced |= 8;                                                 // default: sub-chain parse (decompress.hip, FRONT = 3); "queued" = 64-byte windows + queue
     c->decode_layout = (m && (strcmp(m, "serial") == 0 || strcmp(m, "batched") == 0)) ? 1 : 0;
     // SNAPPIER_HIP_DEC_LDS=<bytes>: dynamic LDS per decode wavefront, an occupancy throttle (160 KiB / bytes blocks per CU)

@@ -251,6 +251,12 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #ifndef SNP_D_PASSES
 #define SNP_D_PASSES 1      // queued mode: extra lane-parallel passes over pending tags before the serial finish
 #endif
+#ifndef SNP_D_RING
+#define SNP_D_RING 4096   // FRONT = 4: bytes of recent output per wavefront kept in an LDS ring (power of two)
+#endif
+#ifndef SNP_D_RING_SPAN
+#define SNP_D_RING_SPAN 1984
+#endif
 #ifndef SNP_D_ROUNDS
 #define SNP_D_ROUNDS 1      // lane-parallel dependency rounds per batch before the rest is finished tag by tag (measured: 1 > 2 > 3)
 #endif
@@ -312,7 +318,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                                                  i32* __restrict__ status, const u8* __restrict__ chunk_type,
                                                  const u32* __restrict__ frag_skip, int redo_only, const u32 b)
 {
-    static_assert(!FRAG || (FRONT != 1 && FRONT != 3), "fragment mode: serial loop or queued front end");
+    static_assert(!FRAG || (FRONT != 1 && FRONT != 3 && FRONT != 4), "fragment mode: serial loop or queued front end");
     if (b >= nblocks) return;
     if (redo_only && status[b] != -1) return;            // decompress_small.hip finished this block (it marks the others -1)
     const u32 lane = lane_id();
@@ -1123,6 +1129,389 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
         w.wv = 0x80000000u;
     }
 
+    // ---- sub-chain parse feeding OUTPUT-granular execution through a ring of recent output in LDS (FRONT = 4) -----------------------
+    // The tag-per-lane batch above moves every tag with 1-4 unaligned 16-byte vector-memory loads and unaligned LDS stores: the texture
+    // path is busy 77 % of the kernel and an unaligned wide LDS access costs the pipe 1-2 cycles per LANE.  Here the lanes own OUTPUT
+    // BYTES instead.  The last kRing bytes of the block's output live in an LDS ring (index = output position + g0, g0 = the block's
+    // misalignment in global memory, so that 16-byte units of the ring are 16-byte units of the output); a batch is still the next <= 64
+    // tags of the list, but it executes in sub-steps of 64 consecutive output bytes, one byte per lane:
+    //   * which tag a byte belongs to: every tag marks the byte before its first one in a bitmap of the batch's span, and a byte's tag is
+    //     the popcount of the marks below it (one broadcast 8-byte LDS read + v_mbcnt per sub-step, no scan);
+    //   * where the byte comes from: ONE dword per tag (`rec`): a copy inside the ring holds -offset, everything else the distance from
+    //     the byte's position to its source in a virtual address space that is simply this wavefront's LDS -- the staged input (literals
+    //     are read where the parse left them) and a buffer of FAR pieces (copies older than the ring and literals beyond the staged
+    //     input: 16-byte pieces loaded from global memory once per batch, tag per lane, the only source loads left on the texture path);
+    //   * bytes whose source lies inside their own sub-step are resolved by pointer doubling over the lanes (ds_bpermute; a lane whose
+    //     source is outside the sub-step is a root; 81 % of the sub-steps of the html-like workload have no such byte and skip this);
+    //   * byte-wide LDS accesses are never serialised (profiles/r04a_microbench_lds_gather.jsonl: ds_read_u8 4.1, ds_write_b8 5.3 cycles
+    //     per wave-instruction per CU in run-structured gathers);
+    //   * the ring leaves for global memory in aligned 16-byte units, one coalesced store per KiB, after every batch.
+    // Everything irregular is left to the serial loop below exactly as in FRONT = 3, after the ring has been flushed.
+    if (FRONT == 4) {
+        constexpr u32 kR = 32;
+        constexpr u32 kW = SNP_WAVE * kR;
+        constexpr u32 kCap = 128;
+        constexpr u32 kRing = SNP_D_RING;                               // bytes of recent output kept in LDS (power of two)
+        constexpr u32 kSpan = SNP_D_RING_SPAN;                          // most output bytes of one batch (<= kRing - 128, multiple of 64, marks fit a dword per lane)
+        constexpr u32 kIn = kRing;                                      // virtual addresses = offsets into c_all
+        constexpr u32 kFar = kIn + kW + 16;
+        constexpr u32 kPos = kFar + 1024;
+        constexpr u32 kMisc = kPos + kW;
+        constexpr u32 kTotal = kMisc + 208 * 4;
+        static_assert((kRing & (kRing - 1)) == 0 && kSpan + 128 <= kRing && kSpan % 64 == 0 && kSpan + 64 <= 2048, "ring geometry");
+        __shared__ __attribute__((aligned(16))) u8 c_all[kTotal];
+        u8* const c_ring = c_all;
+        u8* const c_in = c_all + kIn;
+        u8* const c_far = c_all + kFar;                                 // batches: far pieces; while a super-window is parsed: the overrun bitmaps
+        u16* const c_pos = reinterpret_cast<u16*>(c_all + kPos);
+        u32* const c_misc = reinterpret_cast<u32*>(c_all + kMisc);
+        u32* const c_V = c_misc;                                        // parse: V, T, entry, reach
+        u32* const c_T = c_misc + 64;
+        u32* const c_entry = c_misc + 128;
+        u8* const c_reach = reinterpret_cast<u8*>(c_misc + 192);
+        u32* const c_bits = c_misc;                                     // batches: tag-start marks (64 dwords), one rec per tag
+        u32* const c_rec = c_misc + 64;
+        const u32 r0 = kR * lane;
+        const u32 g0 = static_cast<u32>(reinterpret_cast<uintptr_t>(dst) & 15u);
+        u8* const gbase = dst - g0;                                     // biased positions: pb = output position + g0
+        u32 wbase = ip, ntok = 0, emitted = 0, consumed = 0, staged = 0;
+        u32 wo_b = g0;                                                  // biased position up to which the output has left for global memory
+        u32 fence_b = 0;                                                // ... and is known to have arrived there (FENCED)
+        // ring -> global memory: whole 16-byte units below op (final: every byte below op)
+        auto write_out = [&](bool final) {
+            const u32 lim = op + g0;
+            if (wo_b & 15u) {                                           // the block's first unit (g0 != 0) or the unit a long literal ended in
+                const u32 up = (wo_b + 15u) & ~15u;
+                const u32 e = min(up, lim);
+                if (!final && e != up) return;
+                if (wo_b + lane < e) gbase[wo_b + lane] = c_ring[(wo_b + lane) & (kRing - 1u)];
+                wo_b = e;
+            }
+            const u32 lim16 = lim & ~15u;
+            for (u32 u = wo_b + 16u * lane; u < lim16; u += SNP_WAVE * 16u)
+                *reinterpret_cast<u32x4*>(gbase + u) = *reinterpret_cast<const u32x4*>(c_ring + (u & (kRing - 1u)));
+            if (lim16 > wo_b) wo_b = lim16;
+            if (final && wo_b < lim) {
+                if (wo_b + lane < lim) gbase[wo_b + lane] = c_ring[(wo_b + lane) & (kRing - 1u)];
+                wo_b = lim;
+            }
+        };
+        // One decoded batch: the tags first .. first + 63 of the list, their output starting at position opb.  ne = how many of them the
+        // batch takes (it ends before the first tag that is malformed, a literal of more than 64 bytes, within 16 bytes of the block's
+        // end, beyond kSpan output bytes or out of far units); ne == 0: f0 says what tag 0 is (bit 0 valid, bit 1 a long literal).
+        // The far pieces of the batch are REQUESTED here (fp0..fp3) and stored to c_far when the batch executes.
+        struct RingBatch {
+            u32 ne, span, f0, pos0, len0, body0;                        // wave-uniform
+            u32 D, rel, len, u0;                                        // per lane (= per tag)
+            bool act, farl;
+            u32x4 fp0, fp1, fp2, fp3;
+        };
+        auto decode = [&](const u32 first, const u32 opb, RingBatch& B) {
+            const u32 t = first + lane;
+            const bool have = t < ntok;
+            const u32 pos = have ? c_pos[t] : 0u;
+            u64 q;
+            {
+                const u32 pa = pos & ~3u;                               // two aligned dwords of the staged input (pos < staged - 8)
+                const u32 d0 = *reinterpret_cast<const u32*>(c_in + pa), d1 = *reinterpret_cast<const u32*>(c_in + pa + 4u);
+                q = ((static_cast<u64>(d1) << 32) | d0) >> (8u * (pos & 3u));
+            }
+            const u32 c = static_cast<u32>(q) & 0xffu;
+            const u32 type = c & 3u;
+            const u32 hi6 = c >> 2;
+            const u32 b1234 = static_cast<u32>(q >> 8);
+            const bool is_lit = type == 0;
+            const bool long_lit = is_lit && hi6 >= 60;
+            const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
+            const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
+            const u32 len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);
+            const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
+            const u32 body = pos + 1u + extra;
+            const u32 olen = have ? len : 0u;
+            const u32 incl = wave_inclusive_scan(olen);
+            const u32 ostart = opb + incl - olen;
+            const u32 room = n - wbase - 16u;                           // far pieces over-read 15 bytes
+            const bool lit_ok = ((len - 1u) < room) & (body <= room - len);
+            const bool copy_ok = (off - 1u) < ostart;
+            const bool ok = have & ((is_lit & lit_ok) | (!is_lit & copy_ok)) & (incl + 16u <= expected - opb);
+            const bool big = is_lit & (len > 64u);
+            const bool cand = ok & !big;
+            // far tags: their bytes come from global memory, in 16-byte pieces, into c_far (64 units of 16 bytes per batch)
+            const bool isfar = cand & (is_lit ? body + len > staged : off > kRing - 64u);
+            const u32 units = (len + 15u) >> 4;
+            const u64 f1 = ballot64(isfar), f2 = ballot64(isfar & (len > 16u)), f3 = ballot64(isfar & (len > 32u)), f4 = ballot64(isfar & (len > 48u));
+            const u32 u0 = __builtin_amdgcn_mbcnt_hi(static_cast<u32>(f1 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(f1), 0u)) +
+                           __builtin_amdgcn_mbcnt_hi(static_cast<u32>(f2 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(f2), 0u)) +
+                           __builtin_amdgcn_mbcnt_hi(static_cast<u32>(f3 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(f3), 0u)) +
+                           __builtin_amdgcn_mbcnt_hi(static_cast<u32>(f4 >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<u32>(f4), 0u));
+            const bool fits = !isfar | (u0 + units <= 64u);
+            const u64 okm = ballot64(cand & fits & (incl <= kSpan));
+            const u32 ne = okm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~okm));
+            B.ne = ne;
+            B.f0 = read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), 0);
+            B.pos0 = read_lane(pos, 0);
+            B.len0 = read_lane(len, 0);
+            B.body0 = read_lane(body, 0);
+            B.span = ne ? read_lane(incl, ne ? ne - 1u : 0u) : 0u;
+            const bool act = lane < ne;
+            const u32 rel = ostart - opb;
+            const u32 pb0 = opb + g0;
+            B.act = act;
+            B.rel = rel;
+            B.len = len;
+            B.u0 = u0;
+            // byte at biased position pb of this tag: ring copies read the ring at (pb + D) & (kRing - 1), D = -off; everything else
+            // reads virtual address (pb + D) & 0xfffff, bit 30 of D set
+            const u32 va = isfar ? kFar + 16u * u0 : kIn + body;
+            B.D = (is_lit | isfar) ? (((va - rel - pb0) & 0xfffffu) | 0x40000000u) : 0u - off;
+            const bool farl = act & isfar;
+            B.farl = farl;
+            const u8* const fsrc = is_lit ? src + wbase + body : dst + (ostart - off);
+            if (FENCED) {
+                // a far copy reads global memory this wavefront wrote: its stores must have arrived (in-order vector memory is not relied on)
+                const u32 need = ostart + g0 - off + len + 15u;
+                if (ballot64(farl & !is_lit & (need > fence_b))) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    fence_b = wo_b;
+                }
+            }
+            if (farl) {
+                B.fp0 = ld128u(fsrc);
+                if (len > 16u) B.fp1 = ld128u(fsrc + 16);
+                if (len > 32u) B.fp2 = ld128u(fsrc + 32);
+                if (len > 48u) B.fp3 = ld128u(fsrc + 48);
+            }
+        };
+        // marks, recs and far pieces of a decoded batch -> LDS (the arrays the sub-steps read)
+        auto install = [&](const RingBatch& B) {
+            c_bits[lane] = 0u;
+            lanes_sync_lds();
+            if (B.act && B.rel) atomicOr(&c_bits[(B.rel - 1u) >> 5], 1u << ((B.rel - 1u) & 31u));
+            if (B.act) c_rec[lane] = B.D;
+            if (B.farl) {
+                u8* const fd = c_far + 16u * B.u0;
+                *reinterpret_cast<u32x4*>(fd) = B.fp0;
+                if (B.len > 16u) *reinterpret_cast<u32x4*>(fd + 16) = B.fp1;
+                if (B.len > 32u) *reinterpret_cast<u32x4*>(fd + 32) = B.fp2;
+                if (B.len > 48u) *reinterpret_cast<u32x4*>(fd + 48) = B.fp3;
+            }
+            lanes_sync_lds();
+        };
+        u32 cur_ne = 0, cur_span = 0;
+        bool have_cur = false;
+        DPROF_T0
+        while (st == SNP_OK) {
+            if (emitted == ntok) {
+                // ---- the next super-window (phases A, A', R, T as in FRONT = 3; the staged input stays: literals are read from it) ----
+                ip = wbase + consumed;
+                if (ip + 72 > n || op >= expected) break;
+                wbase = ip;
+                const u32 avail = n - wbase;
+                staged = min(kW, avail);
+                const u32 L = staged - 8u;
+                const u8* const wsrc = src + wbase;
+                {
+                    const u32 oa = lane * 16u, ob = oa + 1024u;
+                    const u32 la = min(oa, avail - 16u), lb = min(ob, avail - 16u);
+                    const u32x4 va = ld128u(wsrc + la), vb = ld128u(wsrc + lb);
+                    st128u(c_in + la, va);
+                    st128u(c_in + lb, vb);
+                }
+                lanes_sync_lds();
+                DPROF_TIME(10);                                         // input staged
+                u32 p = r0, V = 0;
+                {
+                    const u32 lim = min(r0 + kR, L);
+                    while (p < lim) {
+                        V |= 1u << (p - r0);
+                        p += tag_advance_staged(c_in + p);
+                    }
+                }
+                c_V[lane] = V;
+                c_T[lane] = 0;
+                lanes_sync_lds();
+                u32 nx = 64u;
+                u32* const c_O = reinterpret_cast<u32*>(c_far) + lane * (kCap / 32);
+#pragma unroll
+                for (u32 w = 0; w < kCap / 32; ++w) c_O[w] = 0;
+                const u32 obase = p & ~(kR - 1u);
+                for (bool go = p < L; go;) {
+                    const u32 v = c_V[p >> 5];
+                    const u32 adv = tag_advance_staged(c_in + p);
+                    const u32 rel = p - obase;
+                    const bool hit = (v >> (p & 31u)) & 1u;
+                    const bool stop = hit | (rel >= kCap);
+                    nx = stop ? (hit ? p >> 5 : 65u) : nx;
+                    atomicOr(&c_O[min(rel >> 5, kCap / 32 - 1)], stop ? 0u : 1u << (rel & 31u));
+                    p = stop ? p : p + adv;
+                    go = !stop & (p < L);
+                }
+                const u32 m = p;
+                u64 active;
+                u32 entry = 0;
+                {
+                    u32 hop = nx;
+                    bool reached = lane == 0;
+                    c_reach[lane] = reached ? 1 : 0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        lanes_sync_lds();
+                        if (reached && hop < 64u) c_reach[hop] = 1;
+                        lanes_sync_lds();
+                        reached = c_reach[lane] != 0;
+                        const u32 h2 = bperm(hop, hop);
+                        hop = hop < 64u ? h2 : hop;
+                    }
+                    if (reached && nx < 64u) c_entry[nx] = m;
+                    lanes_sync_lds();
+                    if (lane) entry = c_entry[lane];
+                    lanes_sync_lds();
+                    active = ballot64(reached);
+                    const u64 ends = ballot64(reached && nx == 64u);
+                    consumed = ends ? read_lane(m, static_cast<u32>(__builtin_ctzll(ends))) : 0u;
+                }
+                if (ballot64(((active >> lane) & 1ull) && nx == 65u)) {
+                    active = 0;
+                    entry = 0;
+                    for (u32 k = 0, e = 0;;) {
+                        active |= 1ull << k;
+                        entry = lane == k ? e : entry;
+                        u32 mk = read_lane(m, k), nk = read_lane(nx, k);
+                        if (nk == 65u) {
+                            nk = 64u;
+                            while (mk < L) {
+                                const u32 v = bcast_first(c_V[mk >> 5]);
+                                if ((v >> (mk & 31u)) & 1u) { nk = mk >> 5; break; }
+                                if (lane == 0) atomicOr(&c_T[mk >> 5], 1u << (mk & 31u));
+                                mk += bcast_first(tag_advance_staged(c_in + mk));
+                            }
+                        }
+                        if (nk >= 64u) { consumed = mk; break; }
+                        e = mk;
+                        k = nk;
+                    }
+                }
+                if ((active >> lane) & 1ull) {
+                    const u32 own = V & ~((1u << (entry & 31u)) - 1u);
+                    const u32 w0 = obase >> 5;
+                    if (own) atomicOr(&c_T[lane], own);
+#pragma unroll
+                    for (u32 w = 0; w < kCap / 32; ++w) {
+                        const u32 ow = c_O[w];
+                        if (ow && w0 + w < SNP_WAVE) atomicOr(&c_T[w0 + w], ow);
+                    }
+                }
+                lanes_sync_lds();
+                const u32 Tw = c_T[lane];
+                const u32 cnt = static_cast<u32>(__builtin_popcount(Tw));
+                const u32 cincl = wave_inclusive_scan(cnt);
+                ntok = read_lane(cincl, 63);
+                u32 t = cincl - cnt, bits = Tw;
+                while (bits) {
+                    c_pos[t++] = static_cast<u16>(r0 + static_cast<u32>(__builtin_ctz(bits)));
+                    bits &= bits - 1u;
+                }
+                lanes_sync_lds();
+                emitted = 0;
+                DPROF_ADD(2, 1);
+                DPROF_TIME(11);                                         // chains, merge, tag list
+            }
+            // ---- batches: the next <= 64 tags of the list each.  The NEXT batch is decoded, and its far pieces requested, before this
+            //      batch's sub-steps run, and installed (marks, recs, far pieces -> LDS) right after them: the one global round trip of a
+            //      batch is spent under the sub-steps of the batch before ----
+            if (!have_cur) {
+                RingBatch cur;
+                decode(emitted, op, cur);
+                if (cur.ne == 0) {
+                    write_out(true);                                    // the ring holds the newest bytes: global memory must, too
+                    if (cur.f0 != 3u) {                                 // not ours: the serial loop decides, from this tag on
+                        ip = wbase + cur.pos0;
+                        emitted = ntok = consumed = 0;
+                        wbase = ip;
+                        break;
+                    }
+                    // a literal of more than 64 bytes: input -> output directly, and its last bytes into the ring
+                    const u32 l0 = cur.len0;
+                    const u8* const ls = src + wbase + cur.body0;
+                    wave_copy(dst + op, ls, l0, lane);
+                    const u32 keep = min(l0, kRing);
+                    const u32 pb = op + g0 + (l0 - keep);
+                    for (u32 i = lane; i < keep; i += SNP_WAVE) c_ring[(pb + i) & (kRing - 1u)] = ls[l0 - keep + i];
+                    lanes_sync_lds();
+                    op += l0;
+                    wo_b = op + g0;
+                    emitted += 1;
+                    continue;
+                }
+                install(cur);
+                cur_ne = cur.ne;
+                cur_span = cur.span;
+                have_cur = true;
+                DPROF_TIME(12);                                         // (first batch of a super-window: decode + install, far round trip exposed)
+            }
+            const u32 span = cur_span;
+            const u32 pb0 = op + g0;
+            const u32 bw = c_bits[lane];                                // the marks, a dword per lane: sub-steps pick theirs with v_readlane
+            DPROF_ADD(0, 1);
+            DPROF_ADD(1, cur_ne);
+            write_out(false);                                           // everything before this batch
+            DPROF_TIME(15);
+            RingBatch nxt;
+            bool have_nxt = false;
+            if (emitted + cur_ne < ntok) {
+                decode(emitted + cur_ne, op + span, nxt);
+                have_nxt = nxt.ne != 0;
+            }
+            DPROF_TIME(13);                                             // the next batch: tag bytes, decode, prefix sum, checks, far requests
+            // sub-steps of 64 output bytes
+            u32 tbase = 0;                                              // tag (index in the batch) of the sub-step's first byte
+            auto tag_of = [&](u32 sb) {
+                const u32 w_lo = read_lane(bw, sb >> 5), w_hi = read_lane(bw, (sb >> 5) + 1u);
+                const u32 ti = tbase + __builtin_amdgcn_mbcnt_hi(w_hi, __builtin_amdgcn_mbcnt_lo(w_lo, 0u));
+                tbase += static_cast<u32>(__builtin_popcount(w_lo) + __builtin_popcount(w_hi));
+                return ti;
+            };
+            u32 Dn = c_rec[tag_of(0)];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Dn));           // (nothing is in flight at the loop's head: its waits are its own)
+            for (u32 sb = 0; sb < span; sb += SNP_WAVE) {
+                const u32 D = Dn;
+                Dn = c_rec[tag_of(min(sb + SNP_WAVE, kSpan))];          // (the next sub-step's recs travel with this one's bytes; past the span: any rec)
+                const u32 pr = sb + lane;
+                const bool in = pr < span;
+                const u32 pb = pb0 + pr;
+                const bool ring = static_cast<i32>(D) < 0;
+                const u32 a = (pb + D) & (ring ? kRing - 1u : 0xfffffu);
+                const i32 ptr = static_cast<i32>(lane) + static_cast<i32>(D);   // ring copies: lane - off
+                const bool dep = in & ring & (ptr >= 0);                // the source byte belongs to this sub-step
+                u32 byte = c_all[dep ? 0u : a];                         // (every lane reads: no exec-mask bookkeeping; idle lanes read some byte)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(byte), "+v"(Dn));   // both answers are here before the store below is issued: nothing waits for IT
+                if (ballot64(dep)) {
+                    // pointer doubling over the lanes: a lane whose source is outside the sub-step is a root (bit 8: its byte is known)
+                    DPROF_ADD(4, 1);
+                    u32 p4 = dep ? static_cast<u32>(ptr) << 2 : (lane << 2) | 256u;
+                    do {
+                        p4 = static_cast<u32>(__builtin_amdgcn_ds_bpermute(static_cast<int>(p4), static_cast<int>(p4)));
+                        DPROF_ADD(3, 1);
+                    } while (ballot64((p4 & 256u) == 0u));
+                    byte = static_cast<u32>(__builtin_amdgcn_ds_bpermute(static_cast<int>(p4), static_cast<int>(byte)));
+                }
+                if (in) c_ring[pb & (kRing - 1u)] = static_cast<u8>(byte);
+                lanes_sync_lds();
+            }
+            DPROF_TIME(14);                                             // sub-steps
+            op += span;
+            emitted += cur_ne;
+            if (have_nxt) install(nxt);
+            cur_ne = nxt.ne;
+            cur_span = nxt.span;
+            have_cur = have_nxt;
+            DPROF_TIME(12);                                             // install: marks, recs, far pieces (the wait for them, if any is left)
+        }
+        write_out(true);
+        DPROF_FLUSH;
+        w.wv = 0x80000000u;
+    }
+
     u32 fenced = 0;   // output bytes below this are known to have left the wave's store queue (FENCED only)
 
     // ---- tag loop  (SnappyDecompressor.cs:234-341) -----------------------------------------------------------
@@ -1228,8 +1617,8 @@ __global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_
 // ticket (ctl[1]) until the list is empty -- when the pre-pass finished everything (millions of small blocks) this launch costs
 // microseconds instead of one empty workgroup per block (0.87 of 4.7 ms for 4 M blocks of 256 bytes), and when it finished
 // nothing (64 KiB blocks) the wavefronts simply decode ~20 blocks each, balanced by the tickets.
-template <bool FENCED>
-__global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_CHAIN_WAVES, SNP_D_CHAIN_WAVES))) void k_decompress_chains_list(
+template <bool FENCED, int FRONT>
+__device__ __forceinline__ void decompress_list(
     SNP_D_PARAMS, const u32* __restrict__ list, u32* __restrict__ ctl, u32 sub_cap)
 {
     // 64 sub-lists (decompress_small.hip, append_redo): lane s holds the number of entries before sub-list s.
@@ -1248,13 +1637,32 @@ __global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_
         for (u32 i = first; i < last; ++i) {
             const u32 sub = static_cast<u32>(__builtin_popcountll(ballot64(incl <= i)));   // the sub-list ticket i falls into
             const u32 before = read_lane(incl - mine, sub);
-            decompress_block<FENCED, 3, false>(SNP_D_ARGS, list[static_cast<u64>(sub) * sub_cap + (i - before)]);
+            decompress_block<FENCED, FRONT, false>(SNP_D_ARGS, list[static_cast<u64>(sub) * sub_cap + (i - before)]);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the next block reuses the LDS arrays)
         }
         u32 next = 0;
         if (lane == 0) next = atomicAdd(&ctl[64], grab);
         first = gridDim.x * grab + bcast_first(next);
     }
+}
+
+template <bool FENCED>
+__global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_CHAIN_WAVES, SNP_D_CHAIN_WAVES))) void k_decompress_chains_list(
+    SNP_D_PARAMS, const u32* __restrict__ list, u32* __restrict__ ctl, u32 sub_cap)
+{
+    decompress_list<FENCED, 3>(SNP_D_ARGS, list, ctl, sub_cap);
+}
+
+// FRONT = 4: output-granular execution through an LDS ring (10 KiB of LDS per wavefront: 16 wavefronts per CU).
+template <bool FENCED>
+__global__ __launch_bounds__(SNP_WAVE) void k_decompress_ring(SNP_D_PARAMS)
+{
+    decompress_block<FENCED, 4, false>(SNP_D_ARGS, blockIdx.x);
+}
+template <bool FENCED>
+__global__ __launch_bounds__(SNP_WAVE) void k_decompress_ring_list(SNP_D_PARAMS, const u32* __restrict__ list, u32* __restrict__ ctl, u32 sub_cap)
+{
+    decompress_list<FENCED, 4>(SNP_D_ARGS, list, ctl, sub_cap);
 }
 
 }  // namespace
@@ -1280,6 +1688,15 @@ extern "C" hipError_t snp_launch_decompress_list(const u8* in, const u64* in_off
     if (nblocks == 0) return hipSuccess;
     const unsigned lds_bytes = static_cast<unsigned>(mode >> 8) * 256u;
     const u32* const no_skip = nullptr;
+    if (mode & 32) {                                    // output-granular execution through an LDS ring
+        if (mode & 1)
+            hipLaunchKernelGGL((k_decompress_ring_list<true>), dim3(waves), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks,
+                               out, out_off, out_cap, out_len, status, chunk_type, no_skip, 0, list, ctl, sub_cap);
+        else
+            hipLaunchKernelGGL((k_decompress_ring_list<false>), dim3(waves), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks,
+                               out, out_off, out_cap, out_len, status, chunk_type, no_skip, 0, list, ctl, sub_cap);
+        return hipGetLastError();
+    }
     if (mode & 1)
         hipLaunchKernelGGL((k_decompress_chains_list<true>), dim3(waves), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks,
                            out, out_off, out_cap, out_len, status, chunk_type, no_skip, 0, list, ctl, sub_cap);
@@ -1294,7 +1711,7 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
                                             const u8* chunk_type, int mode, hipStream_t stream, const u32* frag_skip)
 {
     // mode bit 0: FENCED, bit 1: serial-only (no token-parallel front end), bit 2: batches without the execution queue, bit 3: sub-chain parse;
-    // bit 4: only the blocks decompress_small.hip left marked -1;  bits 8..: dynamic LDS bytes / 256 requested per wavefront purely to cap how many blocks a CU decodes at once
+    // bit 4: only the blocks decompress_small.hip left marked -1; bit 5: sub-chain parse + LDS ring (FRONT = 4);  bits 8..: dynamic LDS bytes / 256 requested per wavefront purely to cap how many blocks a CU decodes at once
     if (nblocks == 0) return hipSuccess;
     const unsigned lds_bytes = static_cast<unsigned>(mode >> 8) * 256u;
 #define SNP_LAUNCH_DEC(F, B)                                                                                        \
@@ -1310,6 +1727,15 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
             case 2: case 6: SNP_LAUNCH_FRAG(false, 0); break;
             default: SNP_LAUNCH_FRAG(true, 0); break;
         }
+        return hipGetLastError();
+    }
+    if (mode & 32) {                                    // sub-chain parse + output-granular execution through an LDS ring (FRONT = 4)
+        if (mode & 1)
+            hipLaunchKernelGGL((k_decompress_ring<true>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,
+                               nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr, (mode >> 4) & 1);
+        else
+            hipLaunchKernelGGL((k_decompress_ring<false>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,
+                               nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr, (mode >> 4) & 1);
         return hipGetLastError();
     }
     if (mode & 8) {                                     // sub-chain parse

@@ -136,7 +136,7 @@ def test_big_block_output_too_small(ctx):
 def test_big_block_all_decoder_variants(monkeypatch):
     data = corpus_bytes(3 << 20)
     comp = O.compress(data, O.HASH_CRC32C)
-    for decode in ("chains", "queued", "serial", "batched"):
+    for decode in ("chains", "ring", "queued", "serial", "batched"):
         for fenced in ("0", "1"):
             monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
             monkeypatch.setenv("SNAPPIER_HIP_FENCED", fenced)

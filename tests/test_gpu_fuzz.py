@@ -145,7 +145,7 @@ def corrupt(rng: np.random.Generator, z: np.ndarray) -> np.ndarray:
     return z
 
 
-@pytest.mark.parametrize("decode", ["queued", "chains", "batched", "serial", "small", "small-lanes", "small-team4", "small-team16"])
+@pytest.mark.parametrize("decode", ["queued", "chains", "ring", "batched", "serial", "small", "small-lanes", "small-team4", "small-team16"])
 def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatch):
     if decode.startswith("small"):   # every block first goes through the small-block pre-pass (decompress_small.hip: 8 lanes per block, or the named layout)
         if "-" in decode:
