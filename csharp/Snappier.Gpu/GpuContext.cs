@@ -23,12 +23,20 @@ public sealed class GpuContext : SafeHandle
     public static GpuContext Current =>
         TryGetCurrent(out GpuContext? c) ? c! : throw new InvalidOperationException("libsnappier_hip: no HIP device (snp_ctx_create returned Device)");
 
+    // A failed snp_ctx_create (library missing, no HIP device) is remembered for the process: every later routed call then costs one
+    // volatile read instead of another P/Invoke that fails the same way.  ResetAvailability() forgets it (a device was added, tests).
+    private static volatile bool s_unavailable;
+
+    public static void ResetAvailability() => s_unavailable = false;
+
     public static bool TryGetCurrent(out GpuContext? ctx)
     {
         ctx = t_current;
         if (ctx is { IsInvalid: false, IsClosed: false }) return true;
+        if (s_unavailable) { ctx = null; return false; }
         ctx = Create(DefaultDevice, DefaultHash);
         t_current = ctx;
+        if (ctx is null) s_unavailable = true;
         return ctx is not null;
     }
 

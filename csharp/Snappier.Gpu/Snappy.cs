@@ -11,34 +11,87 @@ public static unsafe class Snappy
 {
     // ---- routing ------------------------------------------------------------------------------------------------------------
     // One host-pointer call into the library costs a fixed ~0.3 ms (decompress) to ~1.5 ms (compress) of launches and PCIe round
-    // trips before the first byte moves, then runs at 25-38 GB/s PCIe-inclusive (profiles/r02p_host_api.jsonl: 64 KiB 0.04 / 0.2 GB/s,
-    // 1 MiB 0.7 / 1.6, 16 MiB 7.4 / 12.6, 256 MiB 25 / 24).  Managed Snappier does ~0.5-1 GB/s compress and ~1-3 GB/s decompress on
-    // one core whatever the size, so a single call breaks even at 1-2 MiB and the GPU is worth its fixed cost from a few MiB on.
-    // Below these thresholds (and whenever no HIP device is usable) the call stays on the managed path; the BYTES are the same
-    // either way (same parse, same TableEntry hash: SnpHash.Crc32C is what managed Snappier uses on x64 / ARM64 .NET 8+).
+    // trips before the first byte moves, then runs PCIe-bound (profiles/r03zz_host_api.jsonl: 1 MiB 0.66 / 1.6 GB/s compress /
+    // decompress, 4 MiB 2.2 / 5.1, 16 MiB 7.4 / 12.5, 256 MiB 24.9 / 24.2, 1 GiB 25.5 / 25.3).  ONE managed Snappier thread does
+    // ~0.5-1 GB/s compress and ~1-2 GB/s decompress whatever the size: a single call is faster on the GPU from 2-4 MiB on.  A host
+    // that keeps ALL its cores busy with independent Snappier calls, though, moves 10-25 GB/s in aggregate (BENCH cpu_baseline legs,
+    // INTEGRATION.md "Where the GPU loses"): against that the PCIe-bound call only wins from ~64 MiB (compress) / ~128 MiB
+    // (decompress) per call, and device-resident callers should use the batch entry points instead.  Hence two presets; the default
+    // is the conservative one.  Below the thresholds (and whenever no HIP device is usable) the call stays on the managed path.
+    // The BYTES are the same on both paths only when the GPU context's hash equals the one managed Snappier picks at run time:
+    // SnpHash.Crc32C = x64 with SSE4.2 / ARM64 with CRC on .NET 8+; elsewhere (older runtimes, ARM without CRC, a Mul context)
+    // managed Snappier emits the Mul bytes -- still valid Snappy, but output then changes with input size across the threshold.
+    // AssertHashMatchesManaged() checks this once and turns the managed routing off (thresholds 0) when the two differ.
     // Many small inputs belong in one batch call instead (SnappyStreamChunkCodec, or snp_compress_batch from a device-resident caller).
 
-    /// <summary>Inputs shorter than this are compressed by managed Snappier (default 4 MiB; 0 = always the GPU).</summary>
-    public static int MinGpuCompressBytes { get; set; } = 4 << 20;
+    /// <summary>Thresholds for "one call must be faster than one managed thread" (4 MiB / 4 MiB).</summary>
+    public static void UsePerCallLatencyRouting() { MinGpuCompressBytes = 4 << 20; MinGpuDecompressBytes = 4 << 20; }
 
-    /// <summary>Blocks that declare fewer bytes than this are decompressed by managed Snappier (default 4 MiB; 0 = always the GPU).</summary>
-    public static int MinGpuDecompressBytes { get; set; } = 4 << 20;
+    /// <summary>Thresholds for "the call must beat what the host's cores do in aggregate" (64 MiB / 128 MiB; the default).</summary>
+    public static void UseHostThroughputRouting() { MinGpuCompressBytes = 64 << 20; MinGpuDecompressBytes = 128 << 20; }
 
-    private static bool UseGpuForCompress(long inputLength) => inputLength >= MinGpuCompressBytes && GpuContext.IsAvailable;
+    /// <summary>Inputs shorter than this are compressed by managed Snappier (default 64 MiB; 0 = always the GPU).</summary>
+    public static int MinGpuCompressBytes { get; set; } = 64 << 20;
+
+    /// <summary>Blocks that declare fewer bytes than this are decompressed by managed Snappier (default 128 MiB; 0 = always the GPU).</summary>
+    public static int MinGpuDecompressBytes { get; set; } = 128 << 20;
+
+    /// <summary>Compresses a probe input on both paths; if the bytes differ (the managed runtime uses another TableEntry hash than the GPU
+    /// context) every size goes to the GPU from now on, so that output never depends on input size.  Returns whether they matched.</summary>
+    public static bool AssertHashMatchesManaged()
+    {
+        if (!GpuContext.IsAvailable) return true;
+        byte[] probe = new byte[70000];
+        for (int i = 0; i < probe.Length; ++i) probe[i] = (byte)((i * 31 + (i >> 7)) & 0x3f);
+        int saved = MinGpuCompressBytes;
+        MinGpuCompressBytes = 0;
+        byte[] gpu = CompressToArray(probe);
+        MinGpuCompressBytes = saved;
+        byte[] managed = global::Snappier.Snappy.CompressToArray(probe);
+        bool same = gpu.AsSpan().SequenceEqual(managed);
+        if (!same) { MinGpuCompressBytes = 0; MinGpuDecompressBytes = 0; }
+        return same;
+    }
+
+    private static bool UseGpuForCompress(long inputLength) => inputLength >= MinGpuCompressBytes && GpuAvailable();
+
+    // GpuContext.IsAvailable never throws (GpuContext.Create swallows a missing library) and remembers a failure; the guard here is for
+    // hosts where even the type initialiser of NativeMethods cannot run.
+    private static bool GpuAvailable()
+    {
+        try { return GpuContext.IsAvailable; }
+        catch (DllNotFoundException) { return false; }
+        catch (EntryPointNotFoundException) { return false; }
+        catch (TypeInitializationException) { return false; }
+    }
 
     private static bool UseGpuForDecompress(ReadOnlySpan<byte> input)
     {
+        if (!GpuAvailable()) return false;                      // first: nothing below may touch the native library on a host without it
         if (MinGpuDecompressBytes > 0)
         {
-            // the declared length decides (VarIntEncoding.Read, host-only): a malformed preamble goes to the managed path, which
-            // throws the reference's own exception for it
-            fixed (byte* pin = input)
-            {
-                if (NativeMethods.snp_get_uncompressed_length(pin, (nuint)input.Length, out uint declared, out _) != SnpStatus.Ok) return false;
-                if (declared < (uint)MinGpuDecompressBytes) return false;
-            }
+            // the declared length decides (VarIntEncoding.Read.cs:38-79, restated in managed code): a malformed preamble goes to the
+            // managed path, which throws the reference's own exception for it
+            if (!TryReadDeclaredLength(input, out uint declared)) return false;
+            if (declared < (uint)MinGpuDecompressBytes) return false;
         }
-        return GpuContext.IsAvailable;
+        return true;
+    }
+
+    private static bool TryReadDeclaredLength(ReadOnlySpan<byte> input, out uint value)
+    {
+        value = 0;
+        int shift = 0;
+        for (int i = 0; i < 5 && i < input.Length; ++i)
+        {
+            uint b = input[i];
+            uint v = b & 0x7fu;
+            if (shift == 28 && v > 0xfu) return false;          // the fifth byte may only carry four bits (Helpers.LeftShiftOverflows)
+            value |= v << shift;
+            if (b < 128) return true;
+            shift += 7;
+        }
+        return false;
     }
 
     /// <summary>Snappy.GetMaxCompressedLength (Snappy.cs:20-24).</summary>
@@ -252,12 +305,22 @@ public static unsafe class Snappy
             _handles = new MemoryHandle[n];
             _block = System.Runtime.InteropServices.Marshal.AllocHGlobal(Math.Max(1, n) * (sizeof(IntPtr) + sizeof(nuint)));
             int i = 0;
-            foreach (ReadOnlyMemory<byte> m in input)
+            try
             {
-                _handles[i] = m.Pin();
-                Pointers[i] = (byte*)_handles[i].Pointer;
-                Lengths[i] = (nuint)m.Length;
-                ++i;
+                foreach (ReadOnlyMemory<byte> m in input)
+                {
+                    _handles[i] = m.Pin();
+                    Pointers[i] = (byte*)_handles[i].Pointer;
+                    Lengths[i] = (nuint)m.Length;
+                    ++i;
+                }
+            }
+            catch
+            {
+                // Pin() of a custom MemoryManager may throw: release what was pinned so far and the native block (MemoryHandle.Dispose on a
+                // default handle is a no-op, so the unpinned tail of _handles is safe to dispose too)
+                Dispose();
+                throw;
             }
         }
 

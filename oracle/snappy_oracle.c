@@ -375,6 +375,12 @@ int orc_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t
             size_t avail = n - ip;
             size_t take = len < avail ? len : avail;               /* :290-297: partial literal, then wait for more input */
             if (take > expected - op) return ORC_ERR_TOO_LONG;     /* Append  :570-573 */
+#ifdef ORACLE_FAST
+            /* bench.py's cpu_baseline only: what Snappier does with one vector move (SnappyDecompressor.cs:262-288: a literal of <= 16
+             * bytes with 16 bytes of slack on both sides is one unaligned 16-byte load + store) */
+            if (take <= 16 && n - ip >= 16 && expected - op >= 16) { uint64_t a = ld64(in + ip), b = ld64(in + ip + 8); memcpy(out + op, &a, 8); memcpy(out + op + 8, &b, 8); }
+            else
+#endif
             memcpy(out + op, in + ip, take);
             op += take;
             ip += take;
@@ -385,6 +391,16 @@ int orc_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t
             else { len = (size_t)(c >> 2) + 1; off = trailer; }
             if (off == 0 || op < off) return ORC_ERR_BAD_OFFSET;   /* AppendFromSelf  :598-601 */
             if (len > expected - op) return ORC_ERR_TOO_LONG;      /* :603-606 */
+#ifdef ORACLE_FAST
+            /* bench.py's cpu_baseline only: CopyHelpers.IncrementalCopy (CopyHelpers.cs:64-230) moves 16 bytes at a time when the
+             * offset allows it and the output has slack, 8 at a time from offset 8 on; shorter offsets (pattern copies) stay byte-wise
+             * here (the reference expands the pattern with a shuffle first).  Same bytes as the loop below in every case. */
+            if (off >= 16 && expected - op >= len + 16) {
+                for (size_t k = 0; k < len; k += 16) { uint64_t a = ld64(out + op - off + k), b = ld64(out + op - off + k + 8); memcpy(out + op + k, &a, 8); memcpy(out + op + k + 8, &b, 8); }
+            } else if (off >= 8 && expected - op >= len + 8) {
+                for (size_t k = 0; k < len; k += 8) { uint64_t a = ld64(out + op - off + k); memcpy(out + op + k, &a, 8); }
+            } else
+#endif
             for (size_t k = 0; k < len; k++) out[op + k] = out[op - off + k];   /* IncrementalCopySlow  CopyHelpers.cs:222-230 */
             op += len;
         }
@@ -532,4 +548,20 @@ void orc_crc32c_batch(const uint8_t* in, const uint64_t* in_off, const uint32_t*
         uint32_t c = orc_crc32c(in + in_off[b], in_len[b]);
         out_crc[b] = masked ? orc_crc32c_mask(c) : c;
     }
+}
+
+/* bench.py's cpu_baseline only: a FOREIGN block codec (C++ snappy's snappy_compress / snappy_uncompress, found with dlopen by the
+ * caller and handed over as a function pointer) run over blocks [first, last) inside one call, so that a thread pool of Python
+ * threads scales (one ctypes call per thread instead of one per block).  Returns the number of blocks the function failed on. */
+typedef int (*orc_foreign_block_fn)(const char* in, size_t n, char* out, size_t* out_len);
+uint64_t orc_foreign_codec_batch(orc_foreign_block_fn fn, const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, uint64_t first,
+                                 uint64_t last, uint8_t* out, const uint64_t* out_off, uint64_t out_cap, uint64_t* out_len)
+{
+    uint64_t bad = 0;
+    for (uint64_t b = first; b < last; b++) {
+        size_t w = (size_t)out_cap;
+        if (fn((const char*)in + in_off[b], (size_t)in_len[b], (char*)out + out_off[b], &w) != 0) bad++;
+        out_len[b] = (uint64_t)w;
+    }
+    return bad;
 }

@@ -10,6 +10,7 @@
 #include <new>
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <string>
 #include <utility>
 #include <vector>
@@ -92,7 +93,8 @@ struct snp_ctx {
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
     DevBuf in, out, meta, work, tables, scan, small, redo;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
-    uint64_t counters[4] = {0, 0, 0, 0};   // snp_ctx_counter
+    uint64_t counters[6] = {0, 0, 0, 0, 0, 0};   // snp_ctx_counter
+    bool table_tries_set = false;   // SNP_OPT_TABLE_PROBE_TRIES / SNAPPIER_HIP_TABLE_TRIES was given: the implicit in-call search honours it as is
     std::string err;
 
     // One launch sequence of the decompressor over nblocks blocks (decompress_small.hip, then decompress.hip).
@@ -128,6 +130,21 @@ struct snp_ctx {
             } else {
                 (void)hipGetLastError();
             }
+            if (!hint_seen && !hint_pending && hint_ready() && hipStreamQuery(stream) == hipSuccess) {
+                // The FIRST batch of a context has no previous batch to go by.  When its stream is idle (nothing queued that a wait would
+                // sit behind), a 10 us sample of this batch's capacities (k_sample_caps: <= 16 384 of them, strided) is read back at once:
+                // a first call of 64 KiB blocks then goes straight to one block per wavefront instead of the pre-pass + list kernel (12.10 vs
+                // 11.55 ms per 10 GiB).  A busy stream keeps the old default (pre-pass): results are the same either way.
+                if (hipMemsetAsync(ctl, 0, 68 * 4, stream) == hipSuccess &&
+                    snp_launch_sample_caps(out_cap, nblocks, small_max, ctl, stream) == hipSuccess &&
+                    hipMemcpyAsync(hint, ctl, 68 * 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess && hint[67]) {
+                    hint_mostly_large = static_cast<u64>(hint[65]) * 2 < hint[67];
+                    hint_mean_cap = static_cast<u32>((static_cast<u64>(hint[66]) << 4) / hint[67]);
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            hint_seen = true;
             const bool chains = (fenced & 8) != 0;
             const bool pinned = small_lanes || small_team_log != 0;          // the caller chose the pre-pass layout: the previous batch is not asked
             const bool prepass = redo_list || !chains || pinned || (!redo_grid && !hint_mostly_large);
@@ -178,7 +195,7 @@ struct snp_ctx {
     }
     u32* hint = nullptr;                                 // pinned: the previous batch's list length
     hipEvent_t hint_ev = nullptr;
-    bool hint_pending = false, hint_mostly_large = false, hint_from_prepass = false;
+    bool hint_pending = false, hint_mostly_large = false, hint_from_prepass = false, hint_seen = false;
     u32 hint_blocks = 0, hint_mean_cap = 256;            // (no history yet: assume 256-byte blocks)
     bool hint_ready()
     {
@@ -302,7 +319,11 @@ struct snp_ctx {
             if (static_cast<uint64_t>(nblocks) <= static_cast<uint64_t>(tp.piece_frags) * tp.n) return true;
             free_pieces();
         }
-        if (bytes < (1ull << 30) || table_tries <= 1 || bytes <= tables.cap) {
+        // The search inside a compress CALL is conservative unless the caller configured it: two workspaces' worth of candidates (one
+        // transient extra workspace, a few hundred ms) -- a request must not take seconds or crowd a shared device.  The thorough
+        // search (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, default 16) belongs to snp_ctx_reserve_compress, a service's start-up.
+        const int tries = (thorough || table_tries_set) ? table_tries : (table_tries < 2 ? table_tries : 2);
+        if (bytes < (1ull << 30) || tries <= 1 || bytes <= tables.cap) {
             if (bytes > tables.cap) {
                 if (tables.p) (void)hipFree(tables.p);
                 tables = DevBuf{};
@@ -310,7 +331,7 @@ struct snp_ctx {
                 const size_t want = bytes >= (1ull << 30) ? bytes + 4096 : bytes + bytes / 4 + 4096;
                 if (!check(hipMalloc(&tables.p, want), "hipMalloc(hash tables)")) { tables.p = nullptr; return false; }
                 tables.cap = want;
-                counters[2] = counters[3] = 0;
+                counters[2] = counters[3] = counters[4] = counters[5] = 0;
             }
             tp = snp_table_pieces{};
             tp.p[0] = static_cast<u32*>(tables.p);
@@ -321,11 +342,14 @@ struct snp_ctx {
         if (tables.p) (void)hipFree(tables.p);           // (a small workspace of earlier calls: the pieces replace it)
         tables = DevBuf{};
         PieceSearch ps{};
-        const u32 piece_frags = ((nblocks + SNP_TABLE_PIECES_MAX - 1) / SNP_TABLE_PIECES_MAX + 63u) / 64u * 64u;
+        // capacity = the batch + 1/16 of slack (at most one slice): a later batch of slightly more fragments must not repeat the search
+        const uint64_t with_slack = static_cast<uint64_t>(nblocks) + nblocks / 16u;
+        const u32 cap_frags = static_cast<u32>(with_slack < slice_fragments ? with_slack : (nblocks > slice_fragments ? nblocks : slice_fragments));
+        const u32 piece_frags = ((cap_frags + SNP_TABLE_PIECES_MAX - 1) / SNP_TABLE_PIECES_MAX + 63u) / 64u * 64u;
         const size_t piece_bytes = static_cast<size_t>(piece_frags) * 65536u;
-        ps.n = (nblocks + piece_frags - 1) / piece_frags;
+        ps.n = (cap_frags + piece_frags - 1) / piece_frags;
         ps.piece_gib = piece_bytes / 1073741824.0;
-        ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(table_tries);
+        ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(tries);
         ps.dbg = getenv("SNAPPIER_HIP_DEBUG") != nullptr;
         if (thorough) ps.patience = 64;                                       // snp_ctx_reserve_compress: the caller has time -- look for a third kind as far as max_cand allows
         size_t free_b = 0, total_b = 0;
@@ -352,6 +376,7 @@ struct snp_ctx {
             return ms;
         };
         std::vector<u32> set;
+        const auto t_search = std::chrono::steady_clock::now();
         const float ms = ps.run(set);
         if (ms < 0) {
             for (u32* q : cand) (void)hipFree(q);
@@ -367,6 +392,8 @@ struct snp_ctx {
             if (!used[k]) (void)hipFree(cand[k]);
         counters[2] = ms < 1e6f ? static_cast<uint64_t>(ms * 1000.0f) : 0;    // (a probe that failed reports 1e30: the set then is whatever the arithmetic picked)
         counters[3] = static_cast<uint64_t>(cand.size());
+        counters[4] = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_search).count());
+        counters[5] = static_cast<uint64_t>(cand.size()) * piece_bytes;       // most bytes the search held at once (all candidates coexist until it ends)
         return true;
     }
     bool use_device() { return check(hipSetDevice(device), "hipSetDevice"); }
@@ -497,14 +524,14 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
     // fragments decoded in parallel (tag_index.hip); 0 = always one wavefront per block
     const char* tt = getenv("SNAPPIER_HIP_TABLE_TRIES");
-    if (tt) c->table_tries = atoi(tt) < 1 ? 1 : atoi(tt) > 16 ? 16 : atoi(tt);
+    if (tt) { c->table_tries = atoi(tt) < 1 ? 1 : atoi(tt) > 16 ? 16 : atoi(tt); c->table_tries_set = true; }
     const char* pm = getenv("SNAPPIER_HIP_PARALLEL_MIN");
     if (pm) c->par_min = static_cast<u32>(strtoul(pm, nullptr, 10));
     *out_ctx = c;
     return SNP_OK;
 }
 
-uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 4) ? c->counters[which] : 0; }
+uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 6) ? c->counters[which] : 0; }
 
 snp_status snp_ctx_reserve_compress(snp_ctx* c, uint32_t nfragments)
 {
@@ -544,6 +571,7 @@ snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
         case SNP_OPT_TABLE_PROBE_TRIES:
             if (v < 1 || v > 16) return SNP_ERR_BAD_ARG;
             c->table_tries = static_cast<int>(v);
+            c->table_tries_set = true;
             return SNP_OK;
         case SNP_OPT_TABLE_PROBE_MAX_BYTES:
             if (v < 0) return SNP_ERR_BAD_ARG;

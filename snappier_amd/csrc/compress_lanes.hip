@@ -741,14 +741,25 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
         if (sper != 64 && sper != 32 && sper != 16) sper = 32;
         const u32 sgrid = (nblocks + sper - 1) / sper;
         const u32 dyn = sper * (small_max + 16u + kStageStride);
+        // (The twin general launch below returns early for batches that are this launch's: if this one cannot be launched -- an LDS request a
+        //  part refuses -- small_max goes back to 0, so that the general launch takes the batch and no block is left unwritten.)
+        bool small_ok = true;
 #define SNP_LAUNCH_SMALL(V)                                                                                                                         \
     do {                                                                                                                                            \
-        if (dyn > 48u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_compress_lanes<V, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn)); \
+        if (dyn > 48u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_compress_lanes<V, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dyn)) != hipSuccess) { \
+            small_ok = false;                                                                                                                       \
+            break;                                                                                                                                  \
+        }                                                                                                                                           \
         hipLaunchKernelGGL((k_compress_lanes<V, 2, true>), dim3(sgrid), dim3(sper), dyn, stream, in, in_off, in_len, nblocks, out, out_off, out_len, status, \
                            emit_varint, *tables, lit_blind, max_len, small_max);                                                                    \
+        small_ok = hipGetLastError() == hipSuccess;                                                                                                 \
     } while (0)
         if (variant == SNP_HASH_CRC32C) SNP_LAUNCH_SMALL(SNP_HASH_CRC32C); else SNP_LAUNCH_SMALL(SNP_HASH_MUL);
 #undef SNP_LAUNCH_SMALL
+        if (!small_ok) {
+            (void)hipGetLastError();
+            small_max = 0;
+        }
     }
 #define SNP_LAUNCH_CL(V, S)                                                                                          \
     hipLaunchKernelGGL((k_compress_lanes<V, S, false>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \

@@ -75,3 +75,19 @@ def gather_payload(compact: torch.Tensor, all_len: torch.Tensor, nblocks: int, d
     if sizes[rank]:
         dist.send(compact[: sizes[rank]].contiguous(), dst=dst, group=group)
     return None
+
+
+def rank_stats(values: dict, device=None, group=None) -> dict:
+    """Per-rank scalars (kernel ms, seconds of workspace search ...) -> {name: {"min", "max", "mean", "per_rank": [...]}} on every rank:
+    one all_gather of a float64 vector.  Lets a multi-GPU bench line be decomposed: which rank was slow, and in which part."""
+    names = sorted(values)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = torch.tensor([float(values[k]) for k in names], dtype=torch.float64, device=device)
+    if world > 1:
+        allv = torch.empty(world * len(names), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allv, mine, group=group)
+        allv = allv.view(world, len(names)).cpu()
+    else:
+        allv = mine.view(1, len(names)).cpu()
+    return {k: {"min": float(allv[:, i].min()), "max": float(allv[:, i].max()), "mean": float(allv[:, i].mean()),
+                "per_rank": [round(float(v), 4) for v in allv[:, i]]} for i, k in enumerate(names)}

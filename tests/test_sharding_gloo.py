@@ -36,8 +36,9 @@ def _worker(rank, world, port, nblocks, q):
                                                                  torch.from_numpy(status.astype(np.int64)), nblocks)
         compact = np.concatenate([out[int(out_off[b]):int(out_off[b]) + int(out_len[b])] for b in range(last - first)])
         payload = sharding.gather_payload(torch.from_numpy(compact), all_len, nblocks, dst=0)
+        stats = sharding.rank_stats({"compress_ms": 10.0 + rank, "decompress_ms": 5.0 - rank, "search_s": 0.5 * rank})   # (stub codec: made-up timings)
         if rank == 0:
-            q.put((all_len.numpy(), all_status.numpy(), offsets.numpy(), payload.numpy()))
+            q.put((all_len.numpy(), all_status.numpy(), offsets.numpy(), payload.numpy(), stats))
     finally:
         dist.destroy_process_group()
 
@@ -62,7 +63,7 @@ def test_two_rank_directory_and_payload_gather():
     procs = [ctx.Process(target=_worker, args=(r, world, port, nblocks, q)) for r in range(world)]
     for p in procs:
         p.start()
-    all_len, all_status, offsets, payload = q.get(timeout=240)
+    all_len, all_status, offsets, payload, stats = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -74,6 +75,9 @@ def test_two_rank_directory_and_payload_gather():
     assert (all_status == 0).all()
     assert offsets.tolist() == np.concatenate([[0], np.cumsum([len(r) for r in ref])[:-1]]).tolist()
     assert payload.tobytes() == b"".join(ref)
+    # the per-rank decomposition bench.py prints at N > 1 (sharding.rank_stats): min / max / mean / per_rank of every scalar
+    assert stats["compress_ms"] == {"min": 10.0, "max": 11.0, "mean": 10.5, "per_rank": [10.0, 11.0]}
+    assert stats["decompress_ms"]["per_rank"] == [5.0, 4.0] and stats["search_s"]["max"] == 0.5
     # and the concatenation decodes block by block at the gathered offsets
     for b in range(nblocks):
         s = int(offsets[b])
