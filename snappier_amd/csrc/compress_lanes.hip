@@ -47,6 +47,9 @@ __device__ __forceinline__ u32 check_bits(u32 bytes) { return (bytes * 0x9E3779B
 // stores (148.3 ms: the two halves of a read-modify-write want the sector to stay in L2 in between) and a 16-byte register window
 // over the input (one input load per ~9 probes: 121.2 ms alone, 112.4 with the exchange -- input requests hit L1 / L2 and are nearly
 // free at the table-rate bound); both were removed again.
+#ifndef SNP_CL_ABLATE_RT
+#define SNP_CL_ABLATE_RT 0   // 1: TIMING-ONLY ablations selectable per launch (SNAPPIER_HIP_CL_ABLATE, bits 8.. of the option word); scripts/ab_compress_ablate.py
+#endif
 __device__ __forceinline__ u32 table_swap(u32* p, u32 v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct LaneCtx {
@@ -183,6 +186,7 @@ constexpr u32 kStageStride = 100;      // bytes of LDS per lane: 96 usable (63 p
 struct OutStage {
     u8* lds;        // this lane's buffer
     u32 flushed;    // output bytes [0, flushed) are in global memory
+    bool mute;      // (SNP_CL_ABLATE_RT, ablation 4: the staged runs are not stored -- timing only)
 };
 
 __device__ __forceinline__ void stage_flush64(const LaneCtx& c, OutStage& st)
@@ -194,7 +198,7 @@ __device__ __forceinline__ void stage_flush64(const LaneCtx& c, OutStage& st)
     for (u32 i = 0; i < 64; i += 16) {
         const snp_u128_unaligned q = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + i);
         const v4u v = {q.v[0], q.v[1], q.v[2], q.v[3]};
-        __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(g + i));
+        if (!(SNP_CL_ABLATE_RT && st.mute)) __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(g + i));
     }
     const snp_u128_unaligned t0 = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + 64);
     const snp_u128_unaligned t1 = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + 80);
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     const bool staged = (lit_blind & 16) != 0;
     const bool t_swap = kSlots == 1 && (lit_blind & 64) != 0;          // probe + insert as one atomic exchange (one probe per trip only)
     bool in_win = (lit_blind & 128) != 0;                              // 16-byte register window over the input for the probe bytes (n >= 32, set below)
-    OutStage stg{(SMALL ? s_dyn + blockDim.x * (small_max + 16u) : s_out) + threadIdx.x * kStageStride, 0};
+    OutStage stg{(SMALL ? s_dyn + blockDim.x * (small_max + 16u) : s_out) + threadIdx.x * kStageStride, 0, SNP_CL_ABLATE_RT && (lit_blind & 0x400) != 0};
 
     LaneCtx c;
     c.dst = out + out_off[b];
@@ -362,6 +366,10 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 if (o > 8u) {
                     win_at = min(at, n - 16u);                          // at <= limit = n - 15: the window is pulled back inside the fragment
                     win = *reinterpret_cast<const snp_u128_unaligned*>(c.src + win_at);
+                    if (SNP_CL_ABLATE_RT && (lit_blind & 0x800)) {              // (ablation 8: the window load once more, the 16 bytes before it)
+                        const snp_u128_unaligned e = *reinterpret_cast<const snp_u128_unaligned*>(c.src + (win_at >= 16 ? win_at - 16 : win_at));
+                        asm volatile("" ::"v"(e.v[0] ^ e.v[3]));
+                    }
                     o = at - win_at;                                    // 0 or 1
                 }
                 const u32 dq = o >> 2, sh = (o & 3u) * 8u;
@@ -399,7 +407,15 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 const u32 dm1 = static_cast<u32>(w0);
                 hm1 = lane_hash<VARIANT>(c, dm1, lut);
                 vm1 = (ip - 1) | check_bits(dm1);
-                c.table[hm1] = vm1;
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x4000)) __builtin_nontemporal_store(vm1, &c.table[hm1]);             // (experiment 64: non-temporal)
+                else if (SNP_CL_ABLATE_RT && (lit_blind & 0x8000)) __hip_atomic_store(&c.table[hm1], vm1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (experiment 128: sc1)
+                else if (!(SNP_CL_ABLATE_RT && (lit_blind & 0x100))) {                      // (ablation 1: the ip - 1 insert is not stored)
+                    // full-size tables: non-temporal -- nothing reads the entry soon, and the probe that one day does is an atomic that goes to
+                    // L2 / memory anyway (same-workspace interleaved A/B 96.46 -> 96.13 ms, profiles/r04g_compress_insert_store_kinds.json;
+                    // an agent-scope (sc1) store: 96.41).  Small tables live in L2 and keep the plain store.
+                    if (tstride == 16384u) __builtin_nontemporal_store(vm1, &c.table[hm1]);
+                    else c.table[hm1] = vm1;
+                }
                 d[0] = static_cast<u32>(w0 >> 8);
             } else {
                 d[0] = static_cast<u32>(w0);
@@ -419,6 +435,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 // the bucket the ip - 1 insert of this same trip just wrote takes that entry from the register instead
                 swapped = legal[0] && h[0] != hm1;
                 cv[0] = !legal[0] ? 0u : swapped ? table_swap(&c.table[h[0]], p[0] | check_bits(d[0])) : vm1;
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x2000) && swapped) {   // (ablation 32: one more exchange + store per probe, elsewhere in this lane's table, net effect none)
+                    u32* const other = &c.table[h[0] ^ 0x2000u];
+                    const u32 keep = table_swap(other, 0u);
+                    *other = keep;
+                }
             } else {
 #pragma unroll
                 for (u32 k = 0; k < kSlots; ++k) cv[k] = legal[k] ? c.table[h[k]] : 0u;   // :329 / :396  (position | check bits)
@@ -482,6 +503,13 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 cb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + wpos);
                 pb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + wp);
                 if (!post) lb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + next_emit);
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x200)) {          // (ablation 2: the three loads once more, 64 bytes further back / on)
+                    const snp_u128_unaligned e0 = *reinterpret_cast<const snp_u128_unaligned*>(c.src + (wpos >= 64 ? wpos - 64 : wpos));
+                    const snp_u128_unaligned e1 = *reinterpret_cast<const snp_u128_unaligned*>(c.src + (wp >= 64 ? wp - 64 : wp));
+                    snp_u128_unaligned e2 = e0;
+                    if (!post) e2 = *reinterpret_cast<const snp_u128_unaligned*>(c.src + (next_emit >= 64 ? next_emit - 64 : next_emit));
+                    asm volatile("" ::"v"(e0.v[0] ^ e1.v[1] ^ e2.v[2]));
+                }
             }
             // in-order resolution: probes before kw missed, kw is decided by the bytes, probes after it did not happen
             bool ended = false;
@@ -719,7 +747,8 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");
     const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
     // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
-    const int lit_blind = (ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0));   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
+    const char* ab = getenv("SNAPPIER_HIP_CL_ABLATE");              // (acts in -DSNP_CL_ABLATE_RT=1 builds only: timing-only ablations, bits 8.. of the option word)
+    const int lit_blind = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0))) | ((SNP_CL_ABLATE_RT && ab) ? (atoi(ab) & 255) << 8 : 0);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
