@@ -233,7 +233,7 @@ def cpu_baseline(raw_sample: np.ndarray, variant: int):
 def traffic_profile():
     """Per-block FETCH_SIZE + WRITE_SIZE of the committed PMC passes (rocprofv3 --pmc, one counter per pass, same workload).
     Replayed, never measured in the bench process: the object says which profile, from which commit, over how many launches."""
-    for cand in ("r03_hbm_traffic.json", "r02p_hbm_traffic.json", "r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
+    for cand in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02p_hbm_traffic.json", "r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 doc = json.load(f)

@@ -24,7 +24,8 @@ hipError_t snp_launch_decompress(const u8*, const u64*, const u32*, u32, u8*, co
 u32 snp_tag_index_entries(u32, u32);
 hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
-                                   hipStream_t);
+                                   hipStream_t, uint16_t*, u32);
+size_t snp_compress_win_table_bytes(u32);
 hipError_t snp_launch_decompress_small(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*,
                                        u32, hipStream_t, u32*, u32*, u32, u32);
 hipError_t snp_launch_sample_caps(const u32*, u32, u32, u32*, hipStream_t);
@@ -90,8 +91,10 @@ struct snp_ctx {
     bool redo_grid = false, redo_list = false;   // SNAPPIER_HIP_REDO=grid|list pins how the pre-pass's leftovers are decoded (default: by how the previous batch went)
     u32 small_team_log = 0;        // SNAPPIER_HIP_SMALL=team4|team8|team16: lanes per block (0 = the kernel's default)
     u32 slice_fragments = 262144;   // fragments per lane-compressor launch (SNAPPIER_HIP_SLICE pins it)
+    u32 win_gtab_min = 0xffffffffu;   // auto mode: window-kernel batches of at least this many fragments would keep their tables in global memory (SNAPPIER_HIP_WIN_GTAB_MIN);
+                                      // never by default: measured +5 % only (36.4 vs 34.6 GB/s at 4 096-16 383 fragments -- the kernel turns texture-path-bound, profiles/r04k_pmc_window_kernel.txt)
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
-    DevBuf in, out, meta, work, tables, scan, small, redo;
+    DevBuf in, out, meta, work, tables, scan, small, redo, win_tables;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
     uint64_t counters[6] = {0, 0, 0, 0, 0, 0};   // snp_ctx_counter
     bool table_tries_set = false;   // SNP_OPT_TABLE_PROBE_TRIES / SNAPPIER_HIP_TABLE_TRIES was given: the implicit in-call search honours it as is
@@ -221,10 +224,22 @@ struct snp_ctx {
         // Measured on MI355X (profiles/r02p_compress_by_batch.jsonl, r02_window_kernel.jsonl): the window kernel (LDS tables, 1024 fragments in flight)
         // runs at the same rate at any batch size and beats the single-token wave kernel everywhere; the lane kernel (HBM
         // tables) needs >= 16 384 fragments in flight before its memory-level parallelism overtakes it.
-        const bool win = compress_mode == 3 || (compress_mode == 0 && nblocks < win_max);
-        if (win)
+        // ... and between the two, from win_gtab_min fragments on, the window kernel keeps its u16 tables in a 256 MiB global-memory workspace that
+        // stays in L2 / Infinity Cache instead of in LDS (compress_win.hip, WinTable): 32 wavefronts per CU instead of 4.
+        const bool win = compress_mode == 3 || compress_mode == 4 || (compress_mode == 0 && nblocks < win_max);
+        if (win) {
+            const bool gtab = compress_mode == 4 || (compress_mode == 0 && nblocks >= win_gtab_min);
+            uint16_t* tabs = nullptr;
+            u32 slots = 0;
+            if (gtab) {
+                slots = persistent_waves();
+                if (nblocks < slots) slots = nblocks;
+                if (!ensure(win_tables, snp_compress_win_table_bytes(slots), "hipMalloc(window tables)")) return false;
+                tabs = static_cast<uint16_t*>(win_tables.p);
+            }
             return check(snp_launch_compress_win(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant,
-                                                 emit_varint, win_np, stream), "compress (windows) launch");
+                                                 emit_varint, gtab ? 1 : win_np, stream, tabs, slots), "compress (windows) launch");
+        }
         // 64 KiB of table per fragment in flight: very large batches (millions of small blocks) go in slices, so the
         // workspace stays <= 16 GiB; 262 144 fragments per launch still fill the chip many times over
         if (chint && chint_ev && chint_pending && hipEventQuery(chint_ev) == hipSuccess) {
@@ -502,7 +517,9 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     c->dec_lds = dl ? (atoi(dl) / 256) * 256 : kDefaultDecLds;
     // SNAPPIER_HIP_COMPRESS=win|lanes pins the compressor layout (default: by batch size)
     const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
-    c->compress_mode = (cm && strcmp(cm, "lanes") == 0) ? 2 : (cm && strncmp(cm, "win", 3) == 0) ? 3 : 0;
+    c->compress_mode = (cm && strcmp(cm, "lanes") == 0) ? 2 : (cm && strcmp(cm, "wing") == 0) ? 4 : (cm && strncmp(cm, "win", 3) == 0) ? 3 : 0;
+    const char* wg = getenv("SNAPPIER_HIP_WIN_GTAB_MIN");
+    if (wg) c->win_gtab_min = static_cast<u32>(strtoul(wg, nullptr, 10));
     const char* wn = getenv("SNAPPIER_HIP_WIN_NP");
     if (wn) c->win_np = atoi(wn) == 2 ? 2 : 1;
     const char* fs = getenv("SNAPPIER_HIP_FRAME_SCAN");
@@ -561,7 +578,7 @@ snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
             c->small_min_blocks = static_cast<u32>(v);
             return SNP_OK;
         case SNP_OPT_COMPRESS_LAYOUT:
-            if (v != 0 && v != 2 && v != 3) return SNP_ERR_BAD_ARG;
+            if (v != 0 && v != 2 && v != 3 && v != 4) return SNP_ERR_BAD_ARG;
             c->compress_mode = static_cast<int>(v);
             return SNP_OK;
         case SNP_OPT_COMPRESS_WINDOW_MAX_BATCH:
@@ -624,7 +641,7 @@ void snp_ctx_destroy(snp_ctx* c)
     {
         DevGuard dg(c);
         (void)hipStreamSynchronize(c->stream);
-        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan, &c->small, &c->redo})
+        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan, &c->small, &c->redo, &c->win_tables})
             if (b->p) (void)hipFree(b->p);
         c->free_pieces();
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);

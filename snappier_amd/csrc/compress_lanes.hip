@@ -793,8 +793,8 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
 #define SNP_LAUNCH_CL(V, S)                                                                                          \
     hipLaunchKernelGGL((k_compress_lanes<V, S, false>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
                        out_off, out_len, status, emit_varint, *tables, lit_blind, max_len, small_max)
-    if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 1); else SNP_LAUNCH_CL(SNP_HASH_CRC32C, 2); }
-    else { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_MUL, 1); else SNP_LAUNCH_CL(SNP_HASH_MUL, 2); }
+    if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 1); else if (slots >= 4) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 4); else if (slots == 3) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 3); else SNP_LAUNCH_CL(SNP_HASH_CRC32C, 2); }
+    else { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_MUL, 1); else if (slots >= 4) SNP_LAUNCH_CL(SNP_HASH_MUL, 4); else if (slots == 3) SNP_LAUNCH_CL(SNP_HASH_MUL, 3); else SNP_LAUNCH_CL(SNP_HASH_MUL, 2); }
 #undef SNP_LAUNCH_CL
     return hipGetLastError();
 }

@@ -78,7 +78,7 @@ __device__ __forceinline__ u64 bcast_first64(u64 v)
 {
     return (static_cast<u64>(bcast_first(static_cast<u32>(v >> 32))) << 32) | bcast_first(static_cast<u32>(v));
 }
-__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }   // DS ops of one wave execute in order; compiler-only
+__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }   // DS ops of one wave execute in order; compiler-only (inside compress_win_fragment: tab_fence<GTAB>)
 __device__ __forceinline__ u32 log2_floor_w(u32 v) { return 31u - __clz(v); }
 
 struct __attribute__((packed)) snp_u16_unaligned_w { u16 v; };
@@ -300,20 +300,47 @@ __device__ unsigned long long g_wprof[16];
 #define WPROF_T(k)
 #endif
 
-template <int VARIANT, int NP>
-__global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict__ in, const u64* __restrict__ in_off,
-                                                          const u32* __restrict__ in_len, u32 nblocks,
-                                                          u8* __restrict__ out, const u64* __restrict__ out_off,
-                                                          u32* __restrict__ out_len, i32* __restrict__ status,
-                                                          int emit_varint)
+// Where a wavefront's hash table lives.  GTAB = false: 32 KiB of LDS (the north-star layout; 4 fragments per CU, one wavefront per SIMD).
+// GTAB = true: a 32 KiB slot of a global-memory workspace that stays in L2 / Infinity Cache (8 192 slots = 256 MiB) -- the wavefront then
+// needs 3 KiB of LDS and a CU holds 32 of them: the lone wavefront's issue rate (one instruction per ~6 cycles) stops being the bound for
+// batches of more than ~2 000 fragments.  Entries move with agent-scope (sc1) accesses, which bypass the CU's L1, and every point where
+// the LDS form relies on DS operations executing in order drains vmcnt instead: a store is acknowledged by L2 before a lane reads it back.
+template <bool GTAB>
+struct WinTable {
+    u16* p;
+    __device__ __forceinline__ u32 get(u32 i) const
+    {
+        if constexpr (GTAB) return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return p[i];
+    }
+    __device__ __forceinline__ void set(u32 i, u32 v) const
+    {
+        if constexpr (GTAB) __hip_atomic_store(p + i, static_cast<u16>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p[i] = static_cast<u16>(v);
+    }
+    __device__ __forceinline__ void zero8(u32 i) const { *reinterpret_cast<uint4*>(p + i) = make_uint4(0, 0, 0, 0); }
+};
+template <bool GTAB>
+__device__ __forceinline__ void tab_fence()
+{
+    if constexpr (GTAB) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("" ::: "memory");
+}
+
+template <int VARIANT, int NP, bool GTAB>
+__device__ __forceinline__ void compress_win_fragment(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                      const u32* __restrict__ in_len, u32 nblocks,
+                                                      u8* __restrict__ out, const u64* __restrict__ out_off,
+                                                      u32* __restrict__ out_len, i32* __restrict__ status,
+                                                      int emit_varint, const u32 b, u16* gtab)
 {
     constexpr u32 W = 64u * NP;
-    __shared__ u16 table[16384];                                        // HashTable.cs:17-18
+    __shared__ u16 table_lds[GTAB ? 8 : 16384];                         // HashTable.cs:17-18
     __shared__ u16 lut[VARIANT == SNP_HASH_CRC32C ? 1024 : 8];
     __shared__ u64 ring[128];                                           // tokens: position | length << 16 | offset << 32
+    const WinTable<GTAB> table{GTAB ? gtab : table_lds};
+#define lds_fence tab_fence<GTAB>
 
-    const u32 b = blockIdx.x;
-    if (b >= nblocks) return;
     const u32 lane = lane_id();
     const u8* src = in + in_off[b];
     const u32 n = bcast_first(in_len[b]);
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
     if (n >= 15) {                                                      // Constants.InputMarginBytes  :190
         const u32 tsize = n > 16384 ? 16384u : n < 256 ? 256u : (2u << log2_floor_w(n - 1));   // HashTable.cs:57-71
         const u32 mask = 2 * (tsize - 1);                               // :181
-        for (u32 i = lane * 8; i < tsize; i += 64 * 8) *reinterpret_cast<uint4*>(&table[i]) = make_uint4(0, 0, 0, 0);
+        for (u32 i = lane * 8; i < tsize; i += 64 * 8) table.zero8(i);
         u32 hmask = 0;
         if constexpr (VARIANT == SNP_HASH_CRC32C) {
             for (u32 i = lane; i < 1024; i += 64) lut[i] = g_crc_lut_w.v[i];
@@ -439,7 +466,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                 for (int k = 0; k < NP; ++k) h[k] = bucket_of<VARIANT>(X[k][0].v[0], mask, hmask, lut);
                 lds_fence();
 #pragma unroll
-                for (int k = 0; k < NP; ++k) c[k] = table[h[k]];
+                for (int k = 0; k < NP; ++k) c[k] = table.get(h[k]);
                 WPROF_T(9);                                             // hash + table gather
                 u64 HITM[NP], UNRES[NP];
                 {
@@ -587,12 +614,12 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     pub[k] = (PUB[k] >> lane) & 1ull;
-                    if (pub[k]) table[h[k]] = static_cast<u16>(pp[k]);
+                    if (pub[k]) table.set(h[k], pp[k]);
                 }
                 lds_fence();
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    rb[k] = pub[k] ? static_cast<u32>(table[h[k]]) : pp[k];
+                    rb[k] = pub[k] ? table.get(h[k]) : pp[k];
                     bad = bad || rb[k] != pp[k];
                 }
                 if (ballot64(bad)) {
@@ -602,11 +629,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                         bool again = false;
 #pragma unroll
                         for (int k = 0; k < NP; ++k)
-                            if (pub[k] && rb[k] > pp[k]) { table[h[k]] = static_cast<u16>(pp[k]); again = true; }
+                            if (pub[k] && rb[k] > pp[k]) { table.set(h[k], pp[k]); again = true; }
                         if (!ballot64(again)) break;
                         lds_fence();
 #pragma unroll
-                        for (int k = 0; k < NP; ++k) rb[k] = pub[k] ? static_cast<u32>(table[h[k]]) : pp[k];
+                        for (int k = 0; k < NP; ++k) rb[k] = pub[k] ? table.get(h[k]) : pp[k];
                     }
                     u32 q2 = kNone;
 #pragma unroll
@@ -620,7 +647,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                     lds_fence();
 #pragma unroll
                     for (int k = 0; k < NP; ++k)
-                        if (pub[k]) table[h[k]] = static_cast<u16>(c[k]);
+                        if (pub[k]) table.set(h[k], c[k]);
                     lds_fence();
                     u32 last = kNone;
 #pragma unroll
@@ -644,7 +671,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
                         pub[k] = (PUB[k] >> lane) & 1ull;
-                        if (pub[k]) table[h[k]] = static_cast<u16>(pp[k]);
+                        if (pub[k]) table.set(h[k], pp[k]);
                     }
                     lds_fence();
                 }
@@ -693,7 +720,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                 const u32 d = legal ? ld32u(src + p) : 0u;
                 const u32 h = bucket_of<VARIANT>(d, mask, hmask, lut);
                 lds_fence();
-                const u32 c = table[h];
+                const u32 c = table.get(h);
                 const u32 ev = (legal && !is_ins) ? ld32u(src + c) : ~d;
                 const bool hitl = legal && !is_ins && ev == d;
                 const u64 lmask = ballot64(legal);
@@ -704,28 +731,28 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
                 u32 last = is_hit ? first0 + 1 : first0;                // slots [0, last) are this round's events
                 // publish / read back / cut
                 bool pub = lane < last;
-                if (pub) table[h] = static_cast<u16>(p);
+                if (pub) table.set(h, p);
                 lds_fence();
-                u32 rb = pub ? static_cast<u32>(table[h]) : p;
+                u32 rb = pub ? table.get(h) : p;
                 bool cut = false;
                 if (ballot64(rb != p)) {
                     WPROF_ADD(5, 1);
                     for (;;) {
                         const bool again = pub && rb > p;
-                        if (again) table[h] = static_cast<u16>(p);
+                        if (again) table.set(h, p);
                         if (!ballot64(again)) break;
                         lds_fence();
-                        rb = pub ? static_cast<u32>(table[h]) : p;
+                        rb = pub ? table.get(h) : p;
                     }
                     const u64 los = ballot64(pub && rb < p);
                     const u32 q2 = static_cast<u32>(__builtin_ctzll(los));   // los != 0: some lane lost to an earlier one
                     lds_fence();
-                    if (pub) table[h] = static_cast<u16>(c);
+                    if (pub) table.set(h, c);
                     lds_fence();
                     last = q2;
                     cut = true;
                     pub = lane < last;
-                    if (pub) table[h] = static_cast<u16>(p);
+                    if (pub) table.set(h, p);
                     lds_fence();
                 }
                 if (cut) {
@@ -764,6 +791,34 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict_
         status[b] = SNP_OK;
     }
 }
+#undef lds_fence
+
+template <int VARIANT, int NP>
+__global__ __launch_bounds__(SNP_WAVE) void k_compress_win(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                          const u32* __restrict__ in_len, u32 nblocks,
+                                                          u8* __restrict__ out, const u64* __restrict__ out_off,
+                                                          u32* __restrict__ out_len, i32* __restrict__ status,
+                                                          int emit_varint)
+{
+    if (blockIdx.x >= nblocks) return;
+    compress_win_fragment<VARIANT, NP, false>(in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, blockIdx.x, nullptr);
+}
+
+// The same with the table in a global-memory slot (see WinTable): a persistent grid of at most `slots` wavefronts, wavefront w owns slot w
+// of `tables` and takes fragments w, w + grid, w + 2 grid, ...  (waves_per_eu: 58 VGPRs allow eight wavefronts per SIMD)
+template <int VARIANT, int NP>
+__global__ __launch_bounds__(SNP_WAVE) void k_compress_win_g(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                            const u32* __restrict__ in_len, u32 nblocks,
+                                                            u8* __restrict__ out, const u64* __restrict__ out_off,
+                                                            u32* __restrict__ out_len, i32* __restrict__ status,
+                                                            int emit_varint, u16* __restrict__ tables)
+{
+    u16* const mine = tables + static_cast<size_t>(blockIdx.x) * 16384u;
+    for (u32 b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        compress_win_fragment<VARIANT, NP, true>(in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, b, mine);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the next fragment reuses the slot and the LDS arrays)
+    }
+}
 
 // test hook (include/snappier_hip_debug.h): FindMatchLength by the wave, as the kernel uses it (tests/test_gpu_parity.py runs the reference's KATs through it)
 __global__ __launch_bounds__(SNP_WAVE) void k_debug_match_length(const u8* buf, u32 n, u32 p, u32 cand, u32 known, u32* out)
@@ -792,11 +847,22 @@ extern "C" int snp_debug_read_wprof(unsigned long long* out16, int reset)
 }
 #endif
 
+extern "C" size_t snp_compress_win_table_bytes(u32 slots) { return static_cast<size_t>(slots) * 16384u * sizeof(u16); }
+
+// tables == nullptr: the LDS-table kernel, one workgroup per fragment.  Otherwise `slots` wavefronts, each with a 32 KiB table slot in `tables`.
 extern "C" hipError_t snp_launch_compress_win(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                               const u64* out_off, u32* out_len, i32* status, int variant,
-                                              int emit_varint, int np, hipStream_t stream)
+                                              int emit_varint, int np, hipStream_t stream, u16* tables, u32 slots)
 {
     if (nblocks == 0) return hipSuccess;
+    if (tables && slots) {
+        const u32 grid = nblocks < slots ? nblocks : slots;
+        if (variant == SNP_HASH_CRC32C)
+            hipLaunchKernelGGL((k_compress_win_g<SNP_HASH_CRC32C, 1>), dim3(grid), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, tables);
+        else
+            hipLaunchKernelGGL((k_compress_win_g<SNP_HASH_MUL, 1>), dim3(grid), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, tables);
+        return hipGetLastError();
+    }
 #define SNP_LAUNCH_W(V, P)                                                                                            \
     hipLaunchKernelGGL((k_compress_win<V, P>), dim3(nblocks), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, \
                        out, out_off, out_len, status, emit_varint)

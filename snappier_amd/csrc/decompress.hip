@@ -257,6 +257,9 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #ifndef SNP_D_RING_SPAN
 #define SNP_D_RING_SPAN 1984
 #endif
+#ifndef SNP_D_CAP
+#define SNP_D_CAP 128     // sub-chain front end: bytes a chain may overrun its region before the wave takes over (multiple of 32)
+#endif
 #ifndef SNP_D_ROUNDS
 #define SNP_D_ROUNDS 1      // lane-parallel dependency rounds per batch before the rest is finished tag by tag (measured: 1 > 2 > 3)
 #endif
@@ -833,7 +836,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
     if (FRONT == 3) {
         constexpr u32 kR = 32;                                          // input bytes per lane region
         constexpr u32 kW = SNP_WAVE * kR;                               // the super-window
-        constexpr u32 kCap = 128;                                       // a chain may overrun its region by this much before the wave takes over
+        constexpr u32 kCap = SNP_D_CAP;                                       // a chain may overrun its region by this much before the wave takes over
         __shared__ __attribute__((aligned(16))) u8 c_in[kW];            // its bytes; afterwards the tag positions (u16 each, < kW / 2 of them)
         __shared__ __attribute__((aligned(16))) u8 c_stage[SNP_D_STAGE + 64];
         __shared__ u64 c_busy[65];                                      // batches: pending output bytes; while a super-window is built: V and T

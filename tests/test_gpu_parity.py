@@ -375,7 +375,7 @@ def test_decompress_batch_per_block_status(codec):
     assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
 
 
-@pytest.mark.parametrize("layout", ["win", "win-np2", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31", "lanes-opts87-slots1", "lanes-opts215-slots1", "lanes-opts151-slots2"])
+@pytest.mark.parametrize("layout", ["win", "win-np2", "wing", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31", "lanes-opts87-slots1", "lanes-opts215-slots1", "lanes-opts151-slots2"])
 def test_compress_layouts_are_bit_identical(layout, monkeypatch):
     """Both compressor layouts (one fragment per wavefront with the table in LDS -- the window kernel; one fragment per lane with the table
     in an HBM workspace) must give the oracle's bytes on every kind of input, ragged lengths included."""
