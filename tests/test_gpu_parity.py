@@ -889,7 +889,7 @@ def test_frame_decode_device_span_walk(scan, monkeypatch):
 # ------------------------------------------------------------------ full BASELINE size, size-independent properties
 
 @pytest.mark.timeout(1200)
-def test_full_size_config2_roundtrip(codec):
+def test_full_size_config2_roundtrip(codec, monkeypatch):
     """10 GiB of 64 KiB html-like blocks (BASELINE.json configs[1]): decode(encode(x)) == x for every block, every
     status OK, every decoded length 65536, and EVERY one of the 163 840 compressed blocks equals the oracle's (length + CRC-32C of
     the bytes; byte compare on any mismatch) -- through the default context (16-piece workspace, input register window, non-temporal
@@ -910,6 +910,15 @@ def test_full_size_config2_roundtrip(codec):
     assert bool((dlen == 65536).all())
     assert torch.equal(back, raw)
     assert _oracle_all(cd, raw, out, out_off, out_len, nb, O.HASH_CRC32C, "default context") == nb
+    # the same 10 GiB through the output-granular decoder (FRONT = 4, SNAPPIER_HIP_DECODE=ring: not the default, kept as a measured alternative)
+    monkeypatch.setenv("SNAPPIER_HIP_DECODE", "ring")
+    ringc = SB.BlockCodec(0, O.HASH_CRC32C)
+    back.zero_()
+    dlen, dst = ringc.decompress(out, out_off, out_len, back, in_off, in_len)
+    torch.cuda.synchronize()
+    assert int((dst != 0).sum()) == 0 and bool((dlen == 65536).all()) and torch.equal(back, raw)
+    monkeypatch.delenv("SNAPPIER_HIP_DECODE")
+    del ringc
     out2, _oo, out_len2, _st = cd.compress(raw, in_off, in_len, out=torch.empty_like(out))
     torch.cuda.synchronize()
     assert torch.equal(out_len, out_len2)
