@@ -21,9 +21,14 @@ When N > 1 (or with --config5-lines) the SAME run then measures BASELINE.json co
 block-sharded across the ranks -- and reports it as `config5_lines` (codec only / + directory gather / + compaction
 and payload gather to rank 0): one driver command covers the 8-GPU workload the north star names.  Never `value`.
 
-cpu_baseline (rank 0, N = 1): the C oracle (oracle/snappy_oracle.c, a port of the same algorithm; rebuilt on this
-host with -O3 -march=native when gcc is here) on a bounded sample of the same blocks -- 1 thread, min(cores, 64)
-threads (`value`), all cores; CRC-32C alone; libsnappy through dlopen when this host has one; the CPU model string.
+cpu_baseline (rank 0, N = 1): three CPU implementations on a bounded sample of the same blocks, each on 1 thread, min(cores, 64) threads
+and all cores -- the C oracle (oracle/snappy_oracle.c, a port of the same algorithm; rebuilt on this host with -O3 -march=native when gcc
+is here), its -DORACLE_FAST build (16-byte literal / self-copy moves, the scalar stand-in for CopyHelpers.cs:64-230) and C++ snappy through
+dlopen when this host has one; `value` = the fastest BIT-EXACT round trip they offer (best oracle-build compress leg + best decompress leg).
+
+Also in the line (round 4): `value_plain_workspace` (the same kernels through a second context whose hash-table workspace is ONE plain
+allocation: what the placement search is worth), `workspace_search` (candidates, transient bytes and seconds of that search), `per_rank`
+(min / max / mean / per-rank list of the kernel times, the search seconds and the directory gather: decomposes an N > 1 line).
 """
 from __future__ import annotations
 

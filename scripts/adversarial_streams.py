@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Hand-built, legal Snappy streams that no 64 KiB-fragment compressor emits, chosen against the sub-chain decoder:
+"""Hand-built, legal Snappy streams that no 64 KiB-fragment compressor emits, chosen against the sub-chain decoder (HISTORY.md §4.1c):
 tag periods that never put a region's first byte on a tag start, literal bodies made of long-literal tag bytes, copy-4 tags.
 Each stream is checked against the oracle and timed through every decoder front end.   python scripts/adversarial_streams.py [blocks]
 Prints one JSON line per (stream, front end)."""

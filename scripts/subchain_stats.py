@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU statistics model of the sub-chain tag parse of k_decompress<.., FRONT = 3>: how often the guessed
+"""CPU statistics model of the sub-chain tag parse of k_decompress<.., FRONT = 3> (HISTORY.md §4.1c): how often the guessed
 chains of a super-window merge with the true chain, how many loop trips the phases take, how many tokens a super-window
 yields.  Pure Python over oracle-compressed corpus blocks; prints one JSON line per (file, R, run-in).  Design aid only."""
 import json, os, sys

@@ -10,7 +10,7 @@
 //   k_decompress_small      one block per LANE, global memory: the best layout for blocks of <= ~48 bytes (64 blocks per wavefront)
 //   k_decompress_teams<T>   one block per TEAM of T = 4 / 8 / 16 lanes, compressed and decoded bytes in LDS, coalesced I/O
 //   k_sample_caps           what a batch that skipped the pre-pass looked like (the host's policy, capi.hip launch_decompress)
-// Which one runs, and with how much LDS per wavefront, is decided per batch from the previous batch's read-back.
+// Which one runs, and with how much LDS per wavefront, is decided per batch from the previous batch's read-back (HISTORY.md §4.1b).
 //
 // k_decompress_small: every lane decodes its own block, and the loop is shaped so that one tag costs ONE dependent memory round trip:
 //   * the next tag's bytes are requested as soon as this tag's length is known, before its copy is issued;

@@ -1,4 +1,4 @@
-"""Executable CPU model of the sub-chain tag parse of k_decompress_chains (snappier_amd/csrc/decompress.hip, FRONT = 3).
+"""Executable CPU model of the sub-chain tag parse of k_decompress_chains (snappier_amd/csrc/decompress.hip, FRONT = 3; DESIGN.md §4.1, HISTORY.md §4.1c).
 
 TEST INFRASTRUCTURE ONLY.  It restates, lane by lane, what one wavefront does to find the tag starts of a 2 KiB super-window:
   A   lane k walks a chain of tags through region k (32 bytes) from the region's first byte, recording the positions visited (V_k);

@@ -1,4 +1,4 @@
-"""The sub-chain tag parse of the decompressor, as an executable CPU model (tests/subchain_model.py), against the
+"""The sub-chain tag parse of the decompressor (HISTORY.md §4.1c), as an executable CPU model (tests/subchain_model.py), against the
 sequential tag walk it must reproduce: on the corpus, on streams built against it, on corrupted streams and on plain garbage."""
 import importlib.util
 import os
@@ -33,7 +33,7 @@ def test_windows_of_corpus_blocks_equal_the_sequential_walk(name):
         for ip, pos, consumed in M.stream_windows(comp, stats):
             want_pos, want_end = M.sequential(comp[ip:] + bytes(M.W + 16), min(M.W, len(comp) - ip) - 8)
             assert pos == want_pos and consumed == want_end
-        if name == "html" and start == 0:                           # the numbers DESIGN 4.1c quotes for the sizing
+        if name == "html" and start == 0:                           # the numbers DESIGN.md §4.1, HISTORY.md §4.1c quotes for the sizing
             assert 550 < stats["tokens"] / stats["windows"] < 700
             assert stats["active"] / stats["lanes"] > 0.6
 
