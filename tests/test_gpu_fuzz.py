@@ -94,7 +94,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("layout", ["win", "win2", "lanes"])
+@pytest.mark.parametrize("layout", ["win", "win2", "wing", "lanes"])
 @pytest.mark.parametrize("variant", [O.HASH_CRC32C, O.HASH_MUL])
 def test_fuzz_compress_bytes_equal_oracle(layout, variant, monkeypatch):
     monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout)
