@@ -252,10 +252,11 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #define SNP_D_PASSES 1      // queued mode: extra lane-parallel passes over pending tags before the serial finish
 #endif
 #ifndef SNP_D_RING
-#define SNP_D_RING 4096   // FRONT = 4: bytes of recent output per wavefront kept in an LDS ring (power of two)
+#define SNP_D_RING 2048   // FRONT = 4: bytes of recent output per wavefront kept in an LDS ring (power of two).  Measured, 10 GiB html-like: 1 KiB 16.3 ms,
+                          // 2 KiB 15.6, 4 KiB 16.7, 8 KiB 23.6 (22 / 20 / 16 / 11 wavefronts per CU: occupancy against far tags; profiles/r04o_ring_sizes*.txt)
 #endif
 #ifndef SNP_D_RING_SPAN
-#define SNP_D_RING_SPAN 1984
+#define SNP_D_RING_SPAN 1024
 #endif
 #ifndef SNP_D_CAP
 #define SNP_D_CAP 128     // sub-chain front end: bytes a chain may overrun its region before the wave takes over (multiple of 32)
@@ -1135,7 +1136,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
     // ---- sub-chain parse feeding OUTPUT-granular execution through a ring of recent output in LDS (FRONT = 4) -----------------------
     // The tag-per-lane batch above moves every tag with 1-4 unaligned 16-byte vector-memory loads and unaligned LDS stores: the texture
     // path is busy 77 % of the kernel and an unaligned wide LDS access costs the pipe 1-2 cycles per LANE.  Here the lanes own OUTPUT
-    // BYTES instead.  The last kRing bytes of the block's output live in an LDS ring (index = output position + g0, g0 = the block's
+    // BYTES instead.  The last kRing (2 KiB) bytes of the block's output live in an LDS ring (index = output position + g0, g0 = the block's
     // misalignment in global memory, so that 16-byte units of the ring are 16-byte units of the output); a batch is still the next <= 64
     // tags of the list, but it executes in sub-steps of 64 consecutive output bytes, one byte per lane:
     //   * which tag a byte belongs to: every tag marks the byte before its first one in a bitmap of the batch's span, and a byte's tag is
@@ -1155,13 +1156,13 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
         constexpr u32 kW = SNP_WAVE * kR;
         constexpr u32 kCap = 128;
         constexpr u32 kRing = SNP_D_RING;                               // bytes of recent output kept in LDS (power of two)
-        constexpr u32 kSpan = SNP_D_RING_SPAN;                          // most output bytes of one batch (<= kRing - 128, multiple of 64, marks fit a dword per lane)
+        constexpr u32 kSpan = SNP_D_RING_SPAN;                          // most output bytes of one batch (<= kRing - 158: a far copy's pieces then lie below the written-out frontier; multiple of 64; marks fit a dword per lane)
         constexpr u32 kIn = kRing;                                      // virtual addresses = offsets into c_all
         constexpr u32 kFar = kIn + kW + 16;
         constexpr u32 kPos = kFar + 1024;
         constexpr u32 kMisc = kPos + kW;
         constexpr u32 kTotal = kMisc + 208 * 4;
-        static_assert((kRing & (kRing - 1)) == 0 && kSpan + 128 <= kRing && kSpan % 64 == 0 && kSpan + 64 <= 2048, "ring geometry");
+        static_assert((kRing & (kRing - 1)) == 0 && kSpan + 158 <= kRing && kSpan % 64 == 0 && kSpan + 64 <= 2048, "ring geometry");
         __shared__ __attribute__((aligned(16))) u8 c_all[kTotal];
         u8* const c_ring = c_all;
         u8* const c_in = c_all + kIn;
@@ -1205,11 +1206,12 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
         // The far pieces of the batch are REQUESTED here (fp0..fp3) and stored to c_far when the batch executes.
         struct RingBatch {
             u32 ne, span, f0, pos0, len0, body0;                        // wave-uniform
+            bool late;                                                  // decoded AHEAD and a far copy's source has not left the ring yet: decode again later
             u32 D, rel, len, u0;                                        // per lane (= per tag)
             bool act, farl;
             u32x4 fp0, fp1, fp2, fp3;
         };
-        auto decode = [&](const u32 first, const u32 opb, RingBatch& B) {
+        auto decode = [&](const u32 first, const u32 opb, RingBatch& B, const bool ahead) {
             const u32 t = first + lane;
             const bool have = t < ntok;
             const u32 pos = have ? c_pos[t] : 0u;
@@ -1270,15 +1272,19 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             const bool farl = act & isfar;
             B.farl = farl;
             const u8* const fsrc = is_lit ? src + wbase + body : dst + (ostart - off);
-            if (FENCED) {
-                // a far copy reads global memory this wavefront wrote: its stores must have arrived (in-order vector memory is not relied on)
-                const u32 need = ostart + g0 - off + len + 15u;
+            // A far copy reads global memory this wavefront wrote.  (1) The bytes must have LEFT the ring: a batch decoded here for itself
+            // reads at most kRing - 64 - 143 bytes below its own start, always below wo_b (kSpan + 158 <= kRing); a batch decoded AHEAD (while the
+            // batch before it has not executed) can reach into that batch's output when both are long -- then it is not taken ahead (`late`),
+            // and is decoded again when its turn comes.  (2) FENCED: the stores must also have ARRIVED (in-order vector memory is not relied on).
+            const u32 need = ostart + g0 - off + len + 15u;             // biased end of the bytes the pieces read (15 over-read)
+            B.late = ahead && ballot64(farl & !is_lit & (need > wo_b)) != 0ull;
+            if (FENCED && !B.late) {
                 if (ballot64(farl & !is_lit & (need > fence_b))) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     fence_b = wo_b;
                 }
             }
-            if (farl) {
+            if (farl && !B.late) {
                 B.fp0 = ld128u(fsrc);
                 if (len > 16u) B.fp1 = ld128u(fsrc + 16);
                 if (len > 32u) B.fp2 = ld128u(fsrc + 32);
@@ -1424,7 +1430,8 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             //      batch is spent under the sub-steps of the batch before ----
             if (!have_cur) {
                 RingBatch cur;
-                decode(emitted, op, cur);
+                write_out(false);                                       // (the batch before this one leaves the ring first: this batch's far copies may read it)
+                decode(emitted, op, cur, false);
                 if (cur.ne == 0) {
                     write_out(true);                                    // the ring holds the newest bytes: global memory must, too
                     if (cur.f0 != 3u) {                                 // not ours: the serial loop decides, from this tag on
@@ -1462,8 +1469,8 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
             RingBatch nxt;
             bool have_nxt = false;
             if (emitted + cur_ne < ntok) {
-                decode(emitted + cur_ne, op + span, nxt);
-                have_nxt = nxt.ne != 0;
+                decode(emitted + cur_ne, op + span, nxt, true);
+                have_nxt = nxt.ne != 0 && !nxt.late;
             }
             DPROF_TIME(13);                                             // the next batch: tag bytes, decode, prefix sum, checks, far requests
             // sub-steps of 64 output bytes
@@ -1656,7 +1663,7 @@ __global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_
     decompress_list<FENCED, 3>(SNP_D_ARGS, list, ctl, sub_cap);
 }
 
-// FRONT = 4: output-granular execution through an LDS ring (10 KiB of LDS per wavefront: 16 wavefronts per CU).
+// FRONT = 4: output-granular execution through an LDS ring (8 KiB of LDS per wavefront: 20 wavefronts per CU).
 template <bool FENCED>
 __global__ __launch_bounds__(SNP_WAVE) void k_decompress_ring(SNP_D_PARAMS)
 {

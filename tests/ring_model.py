@@ -58,7 +58,7 @@ class RingExecutor:
     """State of one wavefront while it decodes one block."""
 
     def __init__(self, z: bytes, declared: int, ring: int = 4096, g0: int = 0, span_cap: int = 1984):
-        assert ring & (ring - 1) == 0 and span_cap + 128 <= ring and span_cap % 64 == 0
+        assert ring & (ring - 1) == 0 and span_cap + 158 <= ring and span_cap % 64 == 0
         self.z = np.frombuffer(z, dtype=np.uint8)
         self.RING, self.g0, self.SPAN = ring, g0, span_cap
         self.K_IN = ring
