@@ -57,7 +57,7 @@ def parse_tags(z: bytes):
 class RingExecutor:
     """State of one wavefront while it decodes one block."""
 
-    def __init__(self, z: bytes, declared: int, ring: int = 4096, g0: int = 0, span_cap: int = 1984):
+    def __init__(self, z: bytes, declared: int, ring: int = 2048, g0: int = 0, span_cap: int = 1024):
         assert ring & (ring - 1) == 0 and span_cap + 158 <= ring and span_cap % 64 == 0
         self.z = np.frombuffer(z, dtype=np.uint8)
         self.RING, self.g0, self.SPAN = ring, g0, span_cap
@@ -165,7 +165,7 @@ class RingExecutor:
         return ne
 
 
-def decode_with_ring_model(z: bytes, ring: int = 4096, g0: int = 0, span_cap: int = 1984):
+def decode_with_ring_model(z: bytes, ring: int = 2048, g0: int = 0, span_cap: int = 1024):   # (the kernel's shipped geometry)
     """Decodes a WELL-FORMED Snappy block through the model; returns (bytes, stats)."""
     declared, tags = parse_tags(z)
     ex = RingExecutor(z, declared, ring, g0, span_cap)

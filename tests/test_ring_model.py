@@ -21,7 +21,7 @@ def _blocks():
     yield "short", b"abcabcabcabcabcabcabc" * 3 + b"xyz"
 
 
-@pytest.mark.parametrize("ring,g0,span", [(4096, 0, 1984), (4096, 5, 1984), (2048, 15, 1024), (1024, 9, 512)])
+@pytest.mark.parametrize("ring,g0,span", [(2048, 0, 1024), (2048, 15, 1024), (4096, 5, 1984), (1024, 9, 512)])
 def test_ring_model_equals_sequential_decode(ring, g0, span):
     for name, blk in _blocks():
         z = O.compress(blk)
@@ -32,7 +32,7 @@ def test_ring_model_equals_sequential_decode(ring, g0, span):
 
 def test_ring_model_statistics_match_the_design_numbers():
     """What DESIGN.md quotes for the html-like workload: ~1 000 sub-steps per block, about a fifth of them with a source inside the
-    sub-step, ~1.5 doubling rounds each, and about a quarter of the copies older than a 4 KiB ring."""
+    sub-step, ~1.5 doubling rounds each, and about 40 % of the copies older than the 2 KiB ring."""
     html = read_testdata("html")
     blk = datagen.html_like_blocks(html, 0, 1).tobytes()
     got, st = RM.decode_with_ring_model(O.compress(blk))
@@ -40,7 +40,7 @@ def test_ring_model_statistics_match_the_design_numbers():
     assert 1000 <= st["substeps"] <= 1200
     assert 0.1 < st["dep_substeps"] / st["substeps"] < 0.35
     assert 1.0 <= st["rounds"] / st["dep_substeps"] <= 3.0
-    assert 800 <= st["far_tags"] <= 1600
+    assert 1200 <= st["far_tags"] <= 2400
 
 
 def test_ring_model_pattern_copies_need_log_rounds():
