@@ -218,6 +218,20 @@ __device__ __forceinline__ u32 tag_advance_staged(const u8* at)
     }
     return adv;
 }
+// The same through a 256-entry table in LDS (SNP_D_ADV_LUT, FRONT = 3): entry c = the advance of tag byte c, 0 for a literal with length bytes
+// (0xf0 / 0xf4 / 0xf8 / 0xfc: the rare branch computes it).  One more LDS read per trip instead of ~7 VALU instructions.
+__device__ __forceinline__ u32 tag_advance_lut(const u8* at, const u8* lut)
+{
+    const u32 c = at[0];
+    u32 adv = lut[c];
+    if (__builtin_expect(adv == 0u, 0)) {
+        const u32 ex = (c >> 2) - 59u;
+        const u32 b1234 = reinterpret_cast<const snp_u32_unaligned*>(at + 1)->v;
+        const u32 tr = ex >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * ex);
+        adv = 2u + ex + min(tr, 0x3fffffffu);
+    }
+    return adv;
+}
 __device__ __forceinline__ u64 lds_ld64u(const u8* p) { return reinterpret_cast<const snp_u64_unaligned*>(p)->v; }
 
 #ifndef SNP_D_STAGE
@@ -257,6 +271,9 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #endif
 #ifndef SNP_D_RING_SPAN
 #define SNP_D_RING_SPAN 1024
+#endif
+#ifndef SNP_D_ADV_LUT
+#define SNP_D_ADV_LUT 0   // sub-chain front end (FRONT = 3): tag advance of the chain walks from a 256-byte table in LDS (A/B)
 #endif
 #ifndef SNP_D_CAP
 #define SNP_D_CAP 128     // sub-chain front end: bytes a chain may overrun its region before the wave takes over (multiple of 32)
@@ -841,6 +858,17 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
         __shared__ __attribute__((aligned(16))) u8 c_in[kW];            // its bytes; afterwards the tag positions (u16 each, < kW / 2 of them)
         __shared__ __attribute__((aligned(16))) u8 c_stage[SNP_D_STAGE + 64];
         __shared__ u64 c_busy[65];                                      // batches: pending output bytes; while a super-window is built: V and T
+#if SNP_D_ADV_LUT
+        __shared__ u8 c_adv[256];
+        for (u32 e = lane; e < 256; e += SNP_WAVE) {
+            const u32 t = e & 3u, h = e >> 2;
+            c_adv[e] = static_cast<u8>(t ? (t == 1 ? 2u : t == 2 ? 3u : 5u) : (h >= 60 ? 0u : h + 2u));
+        }
+        lanes_sync_lds();
+#define SNP_ADV(at) tag_advance_lut(at, c_adv)
+#else
+#define SNP_ADV(at) tag_advance_staged(at)
+#endif
         u32* const c_V = reinterpret_cast<u32*>(c_busy);
         u32* const c_T = c_V + SNP_WAVE;
         u16* const c_pos = reinterpret_cast<u16*>(c_in);
@@ -876,7 +904,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                     const u32 lim = min(r0 + kR, L);
                     while (p < lim) {
                         V |= 1u << (p - r0);
-                        p += tag_advance_staged(c_in + p);
+                        p += SNP_ADV(c_in + p);
                         DPROF_TRIP(trips);
                     }
                 }
@@ -893,7 +921,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 const u32 obase = p & ~(kR - 1u);
                 for (bool go = p < L; go;) {
                     const u32 v = c_V[p >> 5];
-                    const u32 adv = tag_advance_staged(c_in + p);
+                    const u32 adv = SNP_ADV(c_in + p);
                     const u32 rel = p - obase;
                     const bool hit = (v >> (p & 31u)) & 1u;
                     const bool stop = hit | (rel >= kCap);
