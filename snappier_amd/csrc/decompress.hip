@@ -275,6 +275,9 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #ifndef SNP_D_ADV_LUT
 #define SNP_D_ADV_LUT 0   // sub-chain front end (FRONT = 3): tag advance of the chain walks from a 256-byte table in LDS (A/B)
 #endif
+#ifndef SNP_D_A2
+#define SNP_D_A2 0        // sub-chain front end (FRONT = 3), phase A: two tags per trip when the first is a copy (A/B)
+#endif
 #ifndef SNP_D_CAP
 #define SNP_D_CAP 128     // sub-chain front end: bytes a chain may overrun its region before the wave takes over (multiple of 32)
 #endif
@@ -902,11 +905,38 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 [[maybe_unused]] u32 trips = 0;
                 {
                     const u32 lim = min(r0 + kR, L);
+#if SNP_D_A2
+                    // Two tags per trip when the first is a COPY (74 % of html tags): its successor can only start 2, 3 or 5 bytes on, so those
+                    // three bytes are read together with the tag byte and the second advance costs no second LDS round trip
+                    // (p < L = staged - 8: the reads stay inside the staged bytes).
+                    while (p < lim) {
+                        const u32 c0 = c_in[p], b2 = c_in[p + 2], b3 = c_in[p + 3], b5 = c_in[p + 5];
+                        V |= 1u << (p - r0);
+                        const u32 t0 = c0 & 3u;
+                        if (__builtin_expect((c0 & 0xf3u) == 0xf0u, 0)) {       // literal with length bytes: the plain form
+                            p += tag_advance_staged(c_in + p);
+                        } else if (t0 == 0) {
+                            p += (c0 >> 2) + 2u;
+                        } else {
+                            const u32 a0 = __builtin_amdgcn_ubfe(0x05030200u, 8u * t0, 8u);
+                            const u32 p1 = p + a0;
+                            const u32 c1 = t0 == 1 ? b2 : t0 == 2 ? b3 : b5;
+                            p = p1;
+                            if (p1 < lim) {
+                                V |= 1u << (p1 - r0);
+                                if (__builtin_expect((c1 & 0xf3u) == 0xf0u, 0)) p = p1 + tag_advance_staged(c_in + p1);
+                                else p = p1 + ((c1 & 3u) ? __builtin_amdgcn_ubfe(0x05030200u, 8u * (c1 & 3u), 8u) : (c1 >> 2) + 2u);
+                            }
+                        }
+                        DPROF_TRIP(trips);
+                    }
+#else
                     while (p < lim) {
                         V |= 1u << (p - r0);
                         p += SNP_ADV(c_in + p);
                         DPROF_TRIP(trips);
                     }
+#endif
                 }
                 DPROF_ADD_MAX(3, trips);                                // loop trips of phase A
                 c_V[lane] = V;
