@@ -11,8 +11,8 @@ public static unsafe class Snappy
 {
     // ---- routing ------------------------------------------------------------------------------------------------------------
     // One host-pointer call into the library costs a fixed ~0.3 ms (decompress) to ~1.5 ms (compress) of launches and PCIe round
-    // trips before the first byte moves, then runs PCIe-bound (profiles/r03zz_host_api.jsonl: 1 MiB 0.66 / 1.6 GB/s compress /
-    // decompress, 4 MiB 2.2 / 5.1, 16 MiB 7.4 / 12.5, 256 MiB 24.9 / 24.2, 1 GiB 25.5 / 25.3).  ONE managed Snappier thread does
+    // trips before the first byte moves, then runs PCIe-bound (profiles/r04zz_host_api.jsonl: 1 MiB 0.66 / 1.6 GB/s compress /
+    // decompress, 4 MiB 2.1 / 5.1, 16 MiB 7.5 / 11.9, 256 MiB 25.0 / 24.2, 1 GiB 25.6 / 25.2).  ONE managed Snappier thread does
     // ~0.5-1 GB/s compress and ~1-2 GB/s decompress whatever the size: a single call is faster on the GPU from 2-4 MiB on.  A host
     // that keeps ALL its cores busy with independent Snappier calls, though, moves 10-25 GB/s in aggregate (BENCH cpu_baseline legs,
     // INTEGRATION.md "Where the GPU loses"): against that the PCIe-bound call only wins from ~64 MiB (compress) / ~128 MiB
@@ -97,9 +97,13 @@ public static unsafe class Snappy
     /// <summary>Snappy.GetMaxCompressedLength (Snappy.cs:20-24).</summary>
     public static int GetMaxCompressedLength(int inputLength)
     {
-        long v = NativeMethods.snp_max_compressed_length(inputLength);
-        if (v < 0) throw new ArgumentOutOfRangeException(nameof(inputLength));
-        return checked((int)v);
+        // Helpers.MaxCompressedLength + VarIntEncoding.MaxLength (Snappy.cs:20-24, Helpers.cs:17-46), in managed arithmetic: the same value as
+        // snp_max_compressed_length (tests/test_capi_cpu.py pins the native one to the formula), and no P/Invoke on a host without the library --
+        // CompressToMemory calls this before any routing decision.
+        if (inputLength < 0) throw new ArgumentOutOfRangeException(nameof(inputLength));
+        long v = 32L + inputLength + inputLength / 6 + 1 + 5;
+        if (v > int.MaxValue) throw new ArgumentOutOfRangeException(nameof(inputLength));
+        return (int)v;
     }
 
     /// <summary>Snappy.Compress (Snappy.cs:37-45): throws ArgumentException when the output span is too small.</summary>
@@ -170,13 +174,10 @@ public static unsafe class Snappy
     /// <summary>Snappy.GetUncompressedLength (Snappy.cs:142-143): InvalidDataException("Invalid stream length") on a bad preamble.</summary>
     public static int GetUncompressedLength(ReadOnlySpan<byte> input)
     {
-        fixed (byte* pin = input)
-        {
-            SnpStatus st = NativeMethods.snp_get_uncompressed_length(pin, (nuint)input.Length, out uint length, out _);
-            ThrowIfFailed(st);
-            if (length > int.MaxValue) throw new InvalidDataException("Invalid stream length");
-            return (int)length;
-        }
+        // managed (VarIntEncoding.Read.cs:16-79; the same rules as snp_get_uncompressed_length, which tests/test_capi_cpu.py holds to the
+        // reference's KATs): nothing that only inspects a preamble may need the native library
+        if (!TryReadDeclaredLength(input, out uint length) || length > int.MaxValue) throw new InvalidDataException("Invalid stream length");
+        return (int)length;
     }
 
     /// <summary>Snappy.Decompress (Snappy.cs:153-162).</summary>
