@@ -85,7 +85,8 @@ snp_status snp_ctx_synchronize(snp_ctx* ctx);
  * which: 0 = large single blocks decoded one wavefront per 64 KiB fragment (snp_try_decompress, tag index),
  *        1 = large single blocks that fell back to the single-wavefront decoder (foreign / malformed streams),
  *        2 = microseconds the chosen hash-table workspace took in the placement probe (512 table-walk probes per fragment; 0: no search ran),
- *        3 = candidate pieces the workspace search allocated. */
+ *        3 = candidate pieces the workspace search allocated,
+ *        4 = microseconds the whole search took (wall clock),  5 = most bytes it held at once (every candidate coexists until it ends). */
 uint64_t snp_ctx_counter(const snp_ctx* ctx, int which);
 
 /* Per-context configuration.  A library loaded into a long-running service is configured through these, per context and at any
@@ -102,7 +103,8 @@ typedef enum snp_option {
     SNP_OPT_SMALL_BLOCK_MAX = 2,        /* bytes; blocks declaring at most this many take the pre-pass (0 = never; default 512) */
     SNP_OPT_SMALL_BLOCK_MIN_BATCH = 3,  /* ... in batches of at least this many blocks (default 4096) */
     /* snp_compress_batch: 0 (default) by batch size -- below SNP_OPT_COMPRESS_WINDOW_MAX_BATCH fragments one fragment per wavefront
-     * with the hash table in LDS, from there on one fragment per lane with the tables in an HBM workspace; 2 / 3 pin the latter / former. */
+     * with the hash table in LDS, from there on one fragment per lane with the tables in an HBM workspace; 2 / 3 pin the latter / former;
+     * 4 = the per-wavefront kernel with its table in a global-memory slot instead of LDS (measured +5 % only: never chosen by itself). */
     SNP_OPT_COMPRESS_LAYOUT = 4,
     SNP_OPT_COMPRESS_WINDOW_MAX_BATCH = 5,   /* default 16384 */
     /* The lane compressor keeps 64 KiB of hash table per fragment of a launch in an HBM workspace the context owns (10.7 GB for
@@ -115,7 +117,10 @@ typedef enum snp_option {
      * second -- or SNP_OPT_TABLE_PROBE_TRIES workspaces' worth of candidates (default 16, 1 = no search: one allocation) have been tried.
      * MEMORY BEHAVIOUR: the candidates coexist until the search ends, within min(half of the device's free memory,
      * SNP_OPT_TABLE_PROBE_MAX_BYTES) (default 0 = no further cap); a process that shares the GPU with other allocators should set
-     * the byte cap (or tries = 1) before its first large compress call.  The losers are freed before the call returns. */
+     * the byte cap (or tries = 1) before its first large compress call.  The losers are freed before the call returns.
+     * WHERE the thorough search runs (round 4): in snp_ctx_reserve_compress.  The search a compress CALL triggers by itself is held to
+     * two workspaces' worth of candidates (one transient extra workspace, a few hundred ms) unless this option was set explicitly, in
+     * which case it is honoured as given -- a request must not take seconds or crowd a shared device behind the caller's back. */
     SNP_OPT_TABLE_PROBE_TRIES = 6,
     SNP_OPT_TABLE_PROBE_MAX_BYTES = 7,
     SNP_OPT_PARALLEL_DECODE_MIN = 8,    /* snp_try_decompress: declared bytes from which ONE block is decoded a wavefront per 64 KiB fragment (0 = never; default 262144) */
