@@ -330,11 +330,14 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731  (recorded on the stream the kernels run on)
     t_comp, t_dec = [], []
 
-    def step(record: bool):
+    def step(record: bool, settle: bool = False):
         e0, e1, e2 = ev(), ev(), ev()
         e0.record()
         _o, _oo, out_len, status = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
         e1.record()
+        if settle:                                          # setup pass only (never timed): the context's FIRST decode then finds its stream idle
+            torch.cuda.synchronize()                        # and decides its layout from a sample of this batch, as a service's first
+                                                            # request does -- it is not queued behind 100 ms of its own compress either
         dlen, dst = cd.decompress(comp, comp_off, out_len, back, in_off, in_len)
         e2.record()
         if distributed:                                     # the one exchange step: (length, status) directory
@@ -344,7 +347,7 @@ def main():
             t_dec.append((e1, e2))
         return out_len, status, dlen, dst
 
-    step(False)                     # setup pass (never timed): first-use allocations, workspace placement search
+    step(False, settle=True)        # setup pass (never timed): first-use allocations, workspace placement search
     for _ in range(args.warmup):
         step(False)
 
