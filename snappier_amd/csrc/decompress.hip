@@ -278,6 +278,9 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #ifndef SNP_D_A2
 #define SNP_D_A2 0        // sub-chain front end (FRONT = 3), phase A: two tags per trip when the first is a copy (A/B)
 #endif
+#ifndef SNP_D_PC
+#define SNP_D_PC 0        // 1: k_decompress_chains becomes the two-wavefront producer / consumer form (FRONT = 5), A/B only
+#endif
 #ifndef SNP_D_CAP
 #define SNP_D_CAP 128     // sub-chain front end: bytes a chain may overrun its region before the wave takes over (multiple of 32)
 #endif
@@ -342,7 +345,7 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                                                  i32* __restrict__ status, const u8* __restrict__ chunk_type,
                                                  const u32* __restrict__ frag_skip, int redo_only, const u32 b)
 {
-    static_assert(!FRAG || (FRONT != 1 && FRONT != 3 && FRONT != 4), "fragment mode: serial loop or queued front end");
+    static_assert(!FRAG || (FRONT != 1 && FRONT != 3 && FRONT != 4 && FRONT != 5), "fragment mode: serial loop or queued front end");
     if (b >= nblocks) return;
     if (redo_only && status[b] != -1) return;            // decompress_small.hip finished this block (it marks the others -1)
     const u32 lane = lane_id();
@@ -1191,6 +1194,374 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
         w.wv = 0x80000000u;
     }
 
+    // ---- FRONT = 5 (experiment, -DSNP_D_PC=1 builds only): the sub-chain front end as a PRODUCER / CONSUMER pair -- a workgroup of two wavefronts
+    // shares one block: wavefront 0 parses super-window k + 1 (phases A, A', R, T -> tag list in LDS, double buffered) while wavefront 1 executes the
+    // batches of super-window k; one workgroup barrier per super-window.  VERDICT r3's "second, cheaper experiment".  Same results as FRONT = 3.
+#if SNP_D_PC
+    if (FRONT == 5) {
+        constexpr u32 kR = 32;
+        constexpr u32 kW = SNP_WAVE * kR;
+        constexpr u32 kCap = SNP_D_CAP;
+        __shared__ __attribute__((aligned(16))) u8 c_in2[2][kW];        // staged input of a super-window, afterwards its tag list (u16 each)
+        __shared__ __attribute__((aligned(16))) u8 c_stage[SNP_D_STAGE + 64];   // executor
+        __shared__ u64 c_busy[65];                                      // executor: pending output bytes of a batch
+        __shared__ __attribute__((aligned(16))) u8 c_pscratch[512 + SNP_WAVE * (kCap / 8)];   // parser: reach flags, entries, overrun bitmaps
+        __shared__ u32 c_VT[2 * SNP_WAVE];                              // parser: V and T
+        __shared__ u32 c_meta[2][4];                                    // per buffer: ntok, wbase, ended
+        __shared__ u32 c_stop;
+        const bool parser = (threadIdx.x >> 6) == 0;
+        u32* const c_V = c_VT;
+        u32* const c_T = c_VT + SNP_WAVE;
+        const u32 r0 = kR * lane;
+        if (threadIdx.x == 0) c_stop = 0;
+        __syncthreads();
+        if (parser) {
+            u32 wbase = ip, consumed = 0, ntok = 0;
+            for (u32 k = 0; st == SNP_OK; ++k) {
+                u8* const c_in = c_in2[k & 1];
+                u16* const c_pos = reinterpret_cast<u16*>(c_in);
+                bool ended = false;
+                {
+                // ---- the next super-window ----
+                ip = wbase + consumed;
+                if (ip + 72 > n) { ended = true; }
+                else {
+                wbase = ip;
+                const u32 avail = n - wbase;
+                const u32 L = min(kW, avail) - 8u;                      // tags may start below L: their 8 bytes lie inside the staged input
+                const u8* const wsrc = src + wbase;
+                {
+                    // 2 x 16 bytes per lane; a piece that would cross the end of the input is pulled back inside it (avail >= 72;
+                    // the bytes it rewrites are the same bytes), pieces beyond it are not needed
+                    const u32 oa = lane * 16u, ob = oa + 1024u;
+                    const u32 la = min(oa, avail - 16u), lb = min(ob, avail - 16u);
+                    const u32x4 va = ld128u(wsrc + la), vb = ld128u(wsrc + lb);
+                    st128u(c_in + la, va);
+                    st128u(c_in + lb, vb);
+                }
+                lanes_sync_lds();
+                DPROF_TIME(10);                                         // input staged
+                // A: the chain from the first byte of the lane's region
+                u32 p = r0, V = 0;
+                [[maybe_unused]] u32 trips = 0;
+                {
+                    const u32 lim = min(r0 + kR, L);
+#if SNP_D_A2
+                    // Two tags per trip when the first is a COPY (74 % of html tags): its successor can only start 2, 3 or 5 bytes on, so those
+                    // three bytes are read together with the tag byte and the second advance costs no second LDS round trip
+                    // (p < L = staged - 8: the reads stay inside the staged bytes).
+                    while (p < lim) {
+                        const u32 c0 = c_in[p], b2 = c_in[p + 2], b3 = c_in[p + 3], b5 = c_in[p + 5];
+                        V |= 1u << (p - r0);
+                        const u32 t0 = c0 & 3u;
+                        if (__builtin_expect((c0 & 0xf3u) == 0xf0u, 0)) {       // literal with length bytes: the plain form
+                            p += tag_advance_staged(c_in + p);
+                        } else if (t0 == 0) {
+                            p += (c0 >> 2) + 2u;
+                        } else {
+                            const u32 a0 = __builtin_amdgcn_ubfe(0x05030200u, 8u * t0, 8u);
+                            const u32 p1 = p + a0;
+                            const u32 c1 = t0 == 1 ? b2 : t0 == 2 ? b3 : b5;
+                            p = p1;
+                            if (p1 < lim) {
+                                V |= 1u << (p1 - r0);
+                                if (__builtin_expect((c1 & 0xf3u) == 0xf0u, 0)) p = p1 + tag_advance_staged(c_in + p1);
+                                else p = p1 + ((c1 & 3u) ? __builtin_amdgcn_ubfe(0x05030200u, 8u * (c1 & 3u), 8u) : (c1 >> 2) + 2u);
+                            }
+                        }
+                        DPROF_TRIP(trips);
+                    }
+#else
+                    while (p < lim) {
+                        V |= 1u << (p - r0);
+                        p += tag_advance_staged(c_in + p);
+                        DPROF_TRIP(trips);
+                    }
+#endif
+                }
+                DPROF_ADD_MAX(3, trips);                                // loop trips of phase A
+                c_V[lane] = V;
+                c_T[lane] = 0;
+                lanes_sync_lds();
+                // A': on past the region until the chain lands on a position its owner visited (one loop exit: the exec-mask
+                // bookkeeping of a divergent loop is scalar work, and the scalar unit is the busiest one in this kernel)
+                u32 nx = 64u;                                           // 64: the chain leaves the super-window, 65: no merge within kCap bytes
+                u32* const c_O = reinterpret_cast<u32*>(c_pscratch + 512) + lane * (kCap / 32);   // overrun positions, a bit each, from obase
+#pragma unroll                                                          // (in the idle stage: keeping them in registers costs 20 instructions per trip)
+                for (u32 w = 0; w < kCap / 32; ++w) c_O[w] = 0;
+                const u32 obase = p & ~(kR - 1u);
+                for (bool go = p < L; go;) {
+                    const u32 v = c_V[p >> 5];
+                    const u32 adv = tag_advance_staged(c_in + p);
+                    const u32 rel = p - obase;
+                    const bool hit = (v >> (p & 31u)) & 1u;
+                    const bool stop = hit | (rel >= kCap);
+                    nx = stop ? (hit ? p >> 5 : 65u) : nx;
+                    atomicOr(&c_O[min(rel >> 5, kCap / 32 - 1)], stop ? 0u : 1u << (rel & 31u));   // (unconditional: no exec-mask bookkeeping)
+                    p = stop ? p : p + adv;
+                    go = !stop & (p < L);
+                    DPROF_TRIP(trips);
+                }
+                const u32 m = p;                                        // where the chain merged, gave up or left
+                DPROF_ADD_MAX(6, trips);                                // ... of A and A' together
+                // R: the lanes on the true chain = the lanes reachable from lane 0 along nx, by pointer doubling (flags through
+                // LDS: a scatter needs its senders masked); each of them tells its successor where it enters.  ~70 wave
+                // instructions instead of a scalar walk of ~14 per lane on the chain (~46 of them on html).
+                u64 active;
+                u32 entry = 0;
+                {
+                    u8* const c_reach = c_pscratch;                        // (the stage is idle while a super-window is built)
+                    u32* const c_entry = reinterpret_cast<u32*>(c_pscratch + SNP_WAVE);
+                    u32 hop = nx;
+                    bool reached = lane == 0;
+                    c_reach[lane] = reached ? 1 : 0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        lanes_sync_lds();
+                        if (reached && hop < 64u) c_reach[hop] = 1;
+                        lanes_sync_lds();
+                        reached = c_reach[lane] != 0;
+                        const u32 h2 = bperm(hop, hop);
+                        hop = hop < 64u ? h2 : hop;
+                    }
+                    if (reached && nx < 64u) c_entry[nx] = m;
+                    lanes_sync_lds();
+                    if (lane) entry = c_entry[lane];
+                    lanes_sync_lds();
+                    active = ballot64(reached);
+                    const u64 ends = ballot64(reached && nx == 64u);    // the lane whose chain leaves the super-window, if the chain gets there
+                    consumed = ends ? read_lane(m, static_cast<u32>(__builtin_ctzll(ends))) : 0u;
+                }
+                if (ballot64(((active >> lane) & 1ull) && nx == 65u)) {
+                    // a chain on the true path did not merge within kCap bytes (rare: ~2 per block on html): follow the path lane by
+                    // lane on the scalar unit instead, walking such a chain on, whole wave, until it merges or leaves
+                    active = 0;
+                    entry = 0;
+                    for (u32 k = 0, e = 0;;) {
+                        active |= 1ull << k;
+                        entry = lane == k ? e : entry;
+                        u32 mk = read_lane(m, k), nk = read_lane(nx, k);
+                        if (nk == 65u) {
+                            DPROF_ADD(7, 1);
+                            nk = 64u;
+                            while (mk < L) {
+                                const u32 v = bcast_first(c_V[mk >> 5]);
+                                if ((v >> (mk & 31u)) & 1u) { nk = mk >> 5; break; }
+                                if (lane == 0) atomicOr(&c_T[mk >> 5], 1u << (mk & 31u));
+                                mk += bcast_first(tag_advance_staged(c_in + mk));
+                                DPROF_ADD(8, 1);
+                            }
+                        }
+                        if (nk >= 64u) { consumed = mk; break; }
+                        e = mk;
+                        k = nk;
+                    }
+                }
+                // T: the true tag starts
+                if ((active >> lane) & 1ull) {
+                    const u32 own = V & ~((1u << (entry & 31u)) - 1u);
+                    const u32 w0 = obase >> 5;
+                    if (own) atomicOr(&c_T[lane], own);
+#pragma unroll
+                    for (u32 w = 0; w < kCap / 32; ++w) {
+                        const u32 ow = c_O[w];
+                        if (ow && w0 + w < SNP_WAVE) atomicOr(&c_T[w0 + w], ow);
+                    }
+                }
+                lanes_sync_lds();
+                const u32 Tw = c_T[lane];
+                const u32 cnt = static_cast<u32>(__builtin_popcount(Tw));
+                const u32 cincl = wave_inclusive_scan(cnt);
+                ntok = read_lane(cincl, 63);
+                lanes_sync_lds();                                       // (every read of c_in is done: the list overwrites it)
+                u32 t = cincl - cnt, bits = Tw;
+                while (bits) {
+                    c_pos[t++] = static_cast<u16>(r0 + static_cast<u32>(__builtin_ctz(bits)));
+                    bits &= bits - 1u;
+                }
+                lanes_sync_lds();
+                DPROF_ADD(2, 1);                                        // super-windows
+                DPROF_ADD(9, __builtin_popcountll(active));             // lanes on the true chain
+                DPROF_TIME(11);                                         // chains, merge, tag list
+                }
+                }
+                if (lane == 0) { c_meta[k & 1][0] = ended ? 0u : ntok; c_meta[k & 1][1] = ended ? ip : wbase; c_meta[k & 1][2] = ended ? 1u : 0u; }
+                __syncthreads();                                        // window k is ready; the executor is done with buffer (k + 1) & 1
+                if (ended || c_stop) break;
+            }
+            return;                                                     // (the executor owns the tail, the status and the length)
+        }
+        {
+            u32 wbase = ip, ntok = 0, emitted = 0;
+            u64 q_pf = 0;
+            u32 pf_at = ~0u;
+            bool e_stop = false;
+            DPROF_T0
+            for (u32 k = 0; st == SNP_OK; ++k) {                        // (a block whose preamble failed: neither wavefront enters its loop)
+                __syncthreads();                                        // the parser has published window k
+                const u32 m_ntok = c_meta[k & 1][0], m_wbase = c_meta[k & 1][1], m_end = c_meta[k & 1][2];
+                u16* const c_pos = reinterpret_cast<u16*>(c_in2[k & 1]);
+                ip = m_wbase;
+                if (m_end) break;
+                if (op >= expected) { e_stop = true; }
+                wbase = m_wbase;
+                ntok = m_ntok;
+                emitted = 0;
+                pf_at = ~0u;
+                while (!e_stop && emitted < ntok) {
+            // ---- one batch: the next <= 64 tags of the list ----
+            const u32 t = emitted + lane;
+            const bool have = t < ntok;
+            const u32 pos = have ? c_pos[t] : 0u;
+#if SNP_D_TOPWAIT
+            const u64 q = pf_at == emitted ? q_pf : ld64u(src + wbase + pos);   // pos < L (idle lanes re-read position 0)
+#else
+            // The tag bytes were requested a batch ago (q_pf); only the first batch of a super-window loads them here.  That load's wait
+            // is kept on ITS path: merged with the prefetched value at a join, the compiler drains vmcnt in EVERY batch -- and what is
+            // still in flight at that point is the previous batch's write-out, so every batch waited ~1 k cycles for its stores to be
+            // acknowledged (the "write-out" that cost 13 % in the ablations was this wait, not the stores).
+            u64 q = q_pf;
+            if (pf_at != emitted) {
+                q = ld64u(src + wbase + pos);                           // pos < L (idle lanes re-read position 0)
+                asm volatile("" : "+v"(q));
+            }
+#endif
+            const u32 c = static_cast<u32>(q) & 0xffu;
+            const u32 type = c & 3u;
+            const u32 hi6 = c >> 2;
+            const u32 b1234 = static_cast<u32>(q >> 8);
+            const bool is_lit = type == 0;
+            const bool long_lit = is_lit && hi6 >= 60;
+            const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
+            const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
+            const u32 len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);
+            const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
+            const u32 body = pos + 1u + extra;                          // a literal's bytes, from wbase
+            const u32 olen = have ? len : 0u;
+            const u32 incl = wave_inclusive_scan(olen);
+            const u32 ostart = op + incl - olen;
+            const u32 room = n - wbase - 16u;                           // lane_copy over-reads 15 bytes
+            const bool lit_ok = ((len - 1u) < room) & (body <= room - len);
+            const bool copy_ok = (off - 1u) < ostart;
+            const bool ok = have & ((is_lit & lit_ok) | (!is_lit & copy_ok)) & (incl + 16u <= expected - op);
+            const bool big = is_lit & (len > 64u);
+            const u64 okm = ballot64(ok & !big & (incl <= SNP_D_STAGE));
+            const u32 ne = okm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~okm));
+            if (ne == 0) {
+                const u32 f0 = read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), 0);
+                if (f0 != 3u) {                                         // not ours: the serial loop decides, from this tag on
+                    ip = wbase + read_lane(pos, 0);
+                    e_stop = true;                                      // (ip is final: the serial loop takes over; the parser is told at the next barrier)
+                    break;
+                }
+                const u32 l0 = read_lane(len, 0);
+                wave_copy(dst + op, src + wbase + read_lane(body, 0), l0, lane);
+                op += l0;
+                emitted += 1;
+                continue;
+            }
+            const bool act = lane < ne;
+            const u32 mark = op;                                        // all output below it is complete
+            const u32 span = read_lane(incl, ne - 1);
+            const bool ready = act && (is_lit || (off >= len && ostart - off + len <= mark));
+            DPROF_TIME(12);                                             // tag bytes (+ whatever the wave still waits for at the batch top), decode, prefix sum, checks
+            if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pf_at = SNP_D_PF ? emitted + ne : ~0u;                      // the next batch's tag bytes travel with this batch's copies
+            if (pf_at < ntok) q_pf = ld64u(src + wbase + (pf_at + lane < ntok ? c_pos[pf_at + lane] : 0u));
+            u8* const my = c_stage + (ostart - mark);
+            const u32 s_lo = ostart - off;
+            // (timing-only ablation 64: every copy source pulled to within 1 KiB below the batch -- what if far back-references cost nothing?
+            //  10.9 vs 11.2 ms, profiles/r03b_decode_far_source_ablation.jsonl: they nearly do already)
+            if (ready && !(SNP_D_ABLATE & 1)) lane_copy2(my, is_lit ? src + wbase + body : dst + ((SNP_D_ABLATE & 64) ? max(s_lo, max(mark, 1024u) - 1024u) : s_lo), (SNP_D_ABLATE & 128) ? min(len, 16u) : len);   // (ablation 128: one 16-byte piece per tag, whatever its length)
+            u64 pend = ballot64(act && !ready);
+            DPROF_ADD(0, 1);
+            DPROF_ADD(1, ne);
+            DPROF_ADD(5, __builtin_popcountll(pend));
+            DPROF_TIME(13);                                             // first pass: source loads, stage stores
+            if (pend) {
+                // second lane-parallel pass: sources inside the batch that no pending tag still has to write
+                bool blocked = off < len || s_lo < mark;                // pattern copies and sources straddling `mark`: finished in order
+                const bool mine = (pend >> lane) & 1ull;
+                if ((SNP_D_ABLATE & 16) == 0 && (pend & (pend - 1))) {
+                    c_busy[lane] = 0ull;
+                    lanes_sync_lds();
+                    if (mine) {
+                        const u32 r = ostart - mark, b0 = r & 63u;
+                        const u64 mk = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+                        atomicOr(reinterpret_cast<unsigned long long*>(&c_busy[r >> 6]), static_cast<unsigned long long>(mk << b0));
+                        if (b0 && (mk >> (64u - b0)))
+                            atomicOr(reinterpret_cast<unsigned long long*>(&c_busy[(r >> 6) + 1]), static_cast<unsigned long long>(mk >> (64u - b0)));
+                    }
+                    lanes_sync_lds();
+                    if (mine && !blocked) {
+                        const u32 lo = s_lo - mark, b0 = lo & 63u;
+                        const u64 mk = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+                        const u64 w0 = c_busy[lo >> 6], w1 = c_busy[(lo >> 6) + 1];
+                        blocked = ((w0 & (mk << b0)) | (b0 ? (w1 & (mk >> (64u - b0))) : 0ull)) != 0ull;
+                    }
+                }
+                const bool ready2 = SNP_D_PASS2 && mine && !blocked;
+                lanes_sync_lds();
+                if (ready2) lane_copy2(my, c_stage + (s_lo - mark), len);
+                pend &= ~ballot64(ready2);
+                DPROF_ADD(4, __builtin_popcountll(pend));
+                // The rest in order, whole wave per tag, a byte per lane.  (This loop runs ~5 times per batch and is mostly scalar
+                // work -- the busiest unit of this kernel -- so the common case, a source inside the stage, is kept to one
+                // LDS read and one LDS write under one exec mask; LDS operations of a wave execute in order.)
+                if (SNP_D_ABLATE & 2) pend = 0;
+                while (pend) {
+                    const u32 f = static_cast<u32>(__builtin_ctzll(pend));
+                    pend &= pend - 1;
+                    const u32 f_o = read_lane(ostart, f), f_off = read_lane(off, f), f_len = read_lane(len, f);
+                    u32 sidx = lane;
+                    if (f_off < f_len) {
+#pragma unroll
+                        for (int sh = 5; sh >= 0; --sh) {
+                            const u32 tt = f_off << sh;
+                            sidx = min(sidx, sidx - tt);
+                        }
+                    }
+                    const u32 rel = f_o - mark;
+                    if (rel >= f_off) {                                 // the whole source lies in this batch
+                        if (lane < f_len) c_stage[rel + lane] = c_stage[rel - f_off + sidx];
+                    } else {                                            // it starts before the batch: those bytes are in global memory
+                        const u32 spos = f_o - f_off + sidx;
+                        u32 byte = 0;
+                        if (lane < f_len) {
+                            if (spos < mark) byte = dst[spos];
+                            else byte = c_stage[spos - mark];
+                        }
+                        if (lane < f_len) c_stage[rel + lane] = static_cast<u8>(byte);
+                    }
+                }
+            }
+            DPROF_TIME(14);                                             // second pass + in-order finish
+            // the whole run, coalesced
+            lanes_sync_lds();
+            u8* const g = dst + mark;
+            if (!(SNP_D_ABLATE & 4)) {
+            for (u32 i = lane * 16; i + 16 <= span; i += SNP_WAVE * 16)
+                *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(c_stage + i);
+            const u32 tail = span & ~15u;
+            if (tail + lane < span) g[tail + lane] = c_stage[tail + lane];
+            }
+            lanes_sync_lds();
+            op += span;
+            emitted += ne;
+            DPROF_TIME(15);                                             // write-out, until the stores are acknowledged
+                }
+                if (e_stop) {
+                    if (lane == 0) c_stop = 1;
+                    __syncthreads();                                    // the barrier the parser is heading for: it reads c_stop behind it and leaves
+                    break;
+                }
+            }
+            DPROF_FLUSH;
+            w.wv = 0x80000000u;
+        }
+    }
+#endif
+
     // ---- sub-chain parse feeding OUTPUT-granular execution through a ring of recent output in LDS (FRONT = 4) -----------------------
     // The tag-per-lane batch above moves every tag with 1-4 unaligned 16-byte vector-memory loads and unaligned LDS stores: the texture
     // path is busy 77 % of the kernel and an unaligned wide LDS access costs the pipe 1-2 cycles per LANE.  Here the lanes own OUTPUT
@@ -1674,11 +2045,19 @@ __global__ __launch_bounds__(SNP_WAVE) SNP_D_OCC void k_decompress(SNP_D_PARAMS)
 #ifndef SNP_D_CHAIN_WAVES
 #define SNP_D_CHAIN_WAVES 8
 #endif
+#if SNP_D_PC
+template <bool FENCED>   // (experiment: two wavefronts per block, parser + executor; see FRONT = 5)
+__global__ __launch_bounds__(2 * SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_CHAIN_WAVES, SNP_D_CHAIN_WAVES))) void k_decompress_chains(SNP_D_PARAMS)
+{
+    decompress_block<FENCED, 5, false>(SNP_D_ARGS, blockIdx.x);
+}
+#else
 template <bool FENCED>
 __global__ __launch_bounds__(SNP_WAVE) __attribute__((amdgpu_waves_per_eu(SNP_D_CHAIN_WAVES, SNP_D_CHAIN_WAVES))) void k_decompress_chains(SNP_D_PARAMS)
 {
     decompress_block<FENCED, 3, false>(SNP_D_ARGS, blockIdx.x);
 }
+#endif
 
 // The same over a LIST of blocks: the blocks the small-block pre-pass (decompress_small.hip) did not finish, which it appended
 // to `list` (ctl[0] = how many).  Persistent: the grid is one chip-full of wavefronts and each takes the next list entry with a
@@ -1808,10 +2187,10 @@ extern "C" hipError_t snp_launch_decompress(const u8* in, const u64* in_off, con
     }
     if (mode & 8) {                                     // sub-chain parse
         if (mode & 1)
-            hipLaunchKernelGGL((k_decompress_chains<true>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,
+            hipLaunchKernelGGL((k_decompress_chains<true>), dim3(nblocks), dim3(SNP_WAVE * (SNP_D_PC ? 2 : 1)), lds_bytes, stream, in, in_off, in_len,
                                nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr, (mode >> 4) & 1);
         else
-            hipLaunchKernelGGL((k_decompress_chains<false>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len,
+            hipLaunchKernelGGL((k_decompress_chains<false>), dim3(nblocks), dim3(SNP_WAVE * (SNP_D_PC ? 2 : 1)), lds_bytes, stream, in, in_off, in_len,
                                nblocks, out, out_off, out_cap, out_len, status, chunk_type, nullptr, (mode >> 4) & 1);
         return hipGetLastError();
     }
