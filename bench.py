@@ -26,6 +26,9 @@ and all cores -- the C oracle (oracle/snappy_oracle.c, a port of the same algori
 is here), its -DORACLE_FAST build (16-byte literal / self-copy moves, the scalar stand-in for CopyHelpers.cs:64-230) and C++ snappy through
 dlopen when this host has one; `value` = the fastest BIT-EXACT round trip they offer (best oracle-build compress leg + best decompress leg).
 
+`roofline.traffic` is MEASURED by the invocation: rank 0 (N = 1) spawns two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then
+WRITE_SIZE; --no-live-traffic skips them and replays the committed profile, which is also the fallback when a pass fails).
+
 Also in the line (round 4): `value_plain_workspace` (the same kernels through a second context whose hash-table workspace is ONE plain
 allocation: what the placement search is worth), `workspace_search` (candidates, transient bytes and seconds of that search), `per_rank`
 (min / max / mean / per-rank list of the kernel times, the search seconds and the directory gather: decomposes an N > 1 line).
@@ -235,6 +238,46 @@ def cpu_baseline(raw_sample: np.ndarray, variant: int):
     }
 
 
+def live_traffic(nb: int, hash_name: str, config: int):
+    """HBM traffic of the codec kernels MEASURED on this box in this bench invocation: two child runs of this script (one untimed setup pass +
+    one step each) under `rocprofv3 --pmc`, ONE counter per pass (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md),
+    no trace domains.  Returns {kernel: {"fetch_bytes", "write_bytes", "launches"}} per LAUNCH (mean over the launches of the child), or a string
+    saying why it could not be measured (the line then falls back to the replayed profile and says so).  Counters are in KB; the calibration of
+    profiles/r01k_pmc_calibration.json applies: scattered narrow accesses (both codec kernels) are counted exactly."""
+    import csv
+    import glob
+    import re
+    import shutil
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return "rocprofv3 not found on this host"
+    acc = {}
+    for counter, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
+        d = tempfile.mkdtemp(prefix="snp_pmc_")
+        cmd = [tool, "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-live-traffic", "--blocks", str(nb), "--hash", hash_name, "--config", str(config)]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(BENCH_NO_PLAIN="1", TMPDIR="/tmp")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        except Exception as e:                                  # noqa: BLE001
+            return f"rocprofv3 --pmc {counter} pass failed: {type(e).__name__}"
+        per = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    m = re.search(r"(k_(?:compress|decompress)[a-z_0-9]*)", r["Kernel_Name"])
+                    if m and r["Counter_Name"] == counter and int(r["Grid_Size"]) >= 64 * 64:      # (not the few-wavefront helpers)
+                        per.setdefault(m.group(1), []).append(float(r["Counter_Value"]) * 1024.0)
+        shutil.rmtree(d, ignore_errors=True)
+        if not per:
+            return f"rocprofv3 --pmc {counter} pass produced no rows for the codec kernels"
+        for k, v in per.items():
+            acc.setdefault(k, {})[key] = sum(v) / len(v)
+            acc[k]["launches"] = len(v)
+    return {k: v for k, v in acc.items() if "fetch_bytes" in v and "write_bytes" in v}
+
+
 def traffic_profile():
     """Per-block FETCH_SIZE + WRITE_SIZE of the committed PMC passes (rocprofv3 --pmc, one counter per pass, same workload).
     Replayed, never measured in the bench process: the object says which profile, from which commit, over how many launches."""
@@ -258,6 +301,7 @@ def main():
     ap.add_argument("--hash", choices=["crc32c", "mul"], default="crc32c")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16384)
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child runs that measure roofline.traffic (replay the committed profile instead)")
     ap.add_argument("--config", type=int, choices=[2, 5], default=2,
                     help="the MEASURED workload (`value`): 2 = BASELINE configs[1] (html-like blocks, the headline); 5 = configs[4] (mixed corpus)")
     ap.add_argument("--config5-lines", action="store_true",
@@ -487,15 +531,26 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         alg = u_bytes + c_bytes                                     # U + C for compress, C + U for decompress
         pmc, pmc_src = traffic_profile()
+        live = None
+        if world == 1 and not args.no_live_traffic and not os.environ.get("BENCH_NO_LIVE_TRAFFIC"):
+            live = live_traffic(nb, args.hash, args.config)      # two child runs under rocprofv3 --pmc: ~15 s each
         def roof(ms, kernel):
             a = alg / (ms * 1e-3) / 1e9
             t = pmc.get(kernel)
-            traffic = int((t["fetch_bytes_per_block"] + t["write_bytes_per_block"]) * nb) if t and args.hash == "crc32c" and args.config == 2 else None
+            if isinstance(live, dict) and kernel in live:
+                traffic = int(live[kernel]["fetch_bytes"] + live[kernel]["write_bytes"])
+                source = {"how": "MEASURED on this box by this invocation: two child runs of bench.py (--steps 1 --warmup 0) under rocprofv3 --pmc, FETCH_SIZE and "
+                                 "WRITE_SIZE in separate passes, mean per launch of this kernel", "launches_profiled": live[kernel]["launches"],
+                          "fetch_bytes": int(live[kernel]["fetch_bytes"]), "write_bytes": int(live[kernel]["write_bytes"]),
+                          "calibration": "profiles/r01k_pmc_calibration.json: scattered narrow accesses are counted exactly (raw counter x 1024)"}
+            else:
+                traffic = int((t["fetch_bytes_per_block"] + t["write_bytes_per_block"]) * nb) if t and args.hash == "crc32c" and args.config == 2 else None
+                source = (dict(pmc_src, how="replayed: per-block FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this workload x blocks of this run; "
+                                            "not measured in this process" + (f" (live measurement: {live})" if isinstance(live, str) else ""),
+                               launches_this_run=args.steps) if traffic and pmc_src else None)
             return {"bound": "hbm", "kernel": kernel, "achieved": round(a, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "traffic_source": (dict(pmc_src, how="replayed: per-block FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this "
-                                                         "workload x blocks of this run; not measured in this process",
-                                            launches_this_run=args.steps) if traffic and pmc_src else None),
+                    "traffic_source": source,
                     "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": int(alg),
                     "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}

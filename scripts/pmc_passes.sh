@@ -10,7 +10,7 @@ for set in "$@"; do
   i=$((i+1))
   d=gpurun_out/pmc_$i
   rm -rf $d
-  BENCH_NO_PLAIN=1 timeout ${PMC_TIMEOUT:-120} rocprofv3 --pmc $set -d $d -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/pmc_$i.log 2>&1
+  BENCH_NO_PLAIN=1 timeout ${PMC_TIMEOUT:-120} rocprofv3 --pmc $set -d $d -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-live-traffic ${BENCH_ARGS:-} > gpurun_out/pmc_$i.log 2>&1
   echo "== pass $i: $set (rc=$?)"
   python - "$d" <<'PY'
 import csv, glob, re, sys, collections
