@@ -259,7 +259,7 @@ def live_traffic(nb: int, hash_name: str, config: int):
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
         env.update(BENCH_NO_PLAIN="1", TMPDIR="/tmp")
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=90, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         except Exception as e:                                  # noqa: BLE001
             return f"rocprofv3 --pmc {counter} pass failed: {type(e).__name__}"
         per = {}
