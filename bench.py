@@ -130,20 +130,26 @@ def time_libsnappy(sample: np.ndarray, nb: int, threads_list, budget_s: float):
             bad.append(r)
 
     def leg(threads, blocks):
+        """one untimed pass (every thread touches its stripe of the output buffers), then the best of two timed passes per direction"""
         blocks = min(blocks, nb)
         edges = np.linspace(0, blocks, threads + 1).astype(np.int64)
         ranges = [(int(edges[i]), int(edges[i + 1])) for i in range(threads) if edges[i + 1] > edges[i]]
+        t_c, t_d = [], []
         with ThreadPoolExecutor(len(ranges)) as ex:
-            t0 = time.perf_counter()
-            list(ex.map(comp_range, ranges))
-            t1 = time.perf_counter()
-            list(ex.map(dec_range, ranges))
-            t2 = time.perf_counter()
+            for rep in range(3):
+                t0 = time.perf_counter()
+                list(ex.map(comp_range, ranges))
+                t1 = time.perf_counter()
+                list(ex.map(dec_range, ranges))
+                t2 = time.perf_counter()
+                if rep:
+                    t_c.append(t1 - t0)
+                    t_d.append(t2 - t1)
         u = float(blocks) * BLOCK
-        return {"threads": threads, "blocks": blocks, "compress_GBps": round(u / (t1 - t0) / 1e9, 3), "decompress_GBps": round(u / (t2 - t1) / 1e9, 3),
-                "round_trip_GBps": round(u / (t2 - t0) / 1e9, 3)}
+        return {"threads": threads, "blocks": blocks, "compress_GBps": round(u / min(t_c) / 1e9, 3), "decompress_GBps": round(u / min(t_d) / 1e9, 3),
+                "round_trip_GBps": round(u / (min(t_c) + min(t_d)) / 1e9, 3)}
 
-    legs = {"1_thread": leg(1, max(256, min(nb, int(budget_s * 0.25e9 / BLOCK))))}
+    legs = {"1_thread": leg(1, max(256, min(nb, int(budget_s * 0.08e9 / BLOCK))))}
     for t in threads_list:
         if t > 1:
             legs[f"{t}_threads"] = leg(t, nb)
@@ -171,28 +177,36 @@ def cpu_baseline(raw_sample: np.ndarray, variant: int):
             O.pyoracle._SO = so
             O.pyoracle._lib = None
 
+    stride = O.max_compressed_length(BLOCK)
+    cbuf = np.empty(nb * stride, dtype=np.uint8)                # reused by every leg: no allocation and no first-touch page faults in a timed pass
+    dbuf = np.empty(raw_sample.size, dtype=np.uint8)
+
     def leg(nthreads: int, blocks: int, budget_s: float):
-        """round trips of the first `blocks` blocks with `nthreads` threads until the budget is spent"""
+        """round trips of the first `blocks` blocks with `nthreads` threads: one untimed pass (every thread touches ITS stripe of the two output buffers: pages
+        land on the thread's NUMA node), then up to 3 timed passes within the budget; the BEST pass of each direction counts (a baseline should not be
+        understated by a noisy neighbour)"""
         blocks = min(blocks, nb)
         s = raw_sample[: blocks * BLOCK]
-        reps, t_c, t_d = 0, 0.0, 0.0
+        out, out_off, out_len, status = O.compress_batch(s, in_off[:blocks], in_len[:blocks], variant, nthreads, out=cbuf)
+        O.decompress_batch(out, out_off, out_len, in_off[:blocks], in_len[:blocks], s.size, nthreads, out=dbuf)
+        reps, t_c, t_d = 0, [], []
         t_start = time.perf_counter()
         while True:
             t0 = time.perf_counter()
-            out, out_off, out_len, status = O.compress_batch(s, in_off[:blocks], in_len[:blocks], variant, nthreads)
+            out, out_off, out_len, status = O.compress_batch(s, in_off[:blocks], in_len[:blocks], variant, nthreads, out=cbuf)
             t1 = time.perf_counter()
-            dec, dlen, dst = O.decompress_batch(out, out_off, out_len, in_off[:blocks], in_len[:blocks], s.size, nthreads)
+            dec, dlen, dst = O.decompress_batch(out, out_off, out_len, in_off[:blocks], in_len[:blocks], s.size, nthreads, out=dbuf)
             t2 = time.perf_counter()
-            t_c += t1 - t0
-            t_d += t2 - t1
+            t_c.append(t1 - t0)
+            t_d.append(t2 - t1)
             reps += 1
             assert (status == 0).all() and (dst == 0).all()
             if reps >= 3 or (time.perf_counter() - t_start) > budget_s:
                 break
-        assert dec.tobytes() == s.tobytes()
-        u = float(blocks) * BLOCK * reps
-        return {"threads": nthreads, "blocks": blocks, "passes": reps, "compress_GBps": round(u / t_c / 1e9, 3), "decompress_GBps": round(u / t_d / 1e9, 3),
-                "round_trip_GBps": round(u / (t_c + t_d) / 1e9, 3)}
+        assert dec[: s.size].tobytes() == s.tobytes()
+        u = float(blocks) * BLOCK
+        return {"threads": nthreads, "blocks": blocks, "passes": reps, "compress_GBps": round(u / min(t_c) / 1e9, 3), "decompress_GBps": round(u / min(t_d) / 1e9, 3),
+                "round_trip_GBps": round(u / (min(t_c) + min(t_d)) / 1e9, 3)}
 
     def legs_of(so, budget):
         use(so)
@@ -230,7 +244,7 @@ def cpu_baseline(raw_sample: np.ndarray, variant: int):
         "compress_GBps": best_c[0], "compress_leg": best_c[1], "decompress_GBps": best_d[0], "decompress_leg": best_d[1],
         "legs": {"oracle": plain, "oracle_fast": fast, "libsnappy": snappy},
         "crc32c_GBps": crc,
-        "sample": f"{nb} of the same html-like 64 KiB blocks (blocks striped over the threads), up to 3 passes per leg; C oracle built {how_plain} and "
+        "sample": f"{nb} of the same html-like 64 KiB blocks (blocks striped over the threads); per leg one untimed pass that touches the reused output buffers, then up to 3 timed passes, the best of each direction counts; C oracle built {how_plain} and "
                   f"{how_fast} (hash = SSE4.2 crc32, as Snappier on x64/.NET 8+); value = the fastest bit-exact legs of the two directions combined",
         "note": "Snappier's C# path is not runnable on this host (no .NET runtime).  The oracle is a C port of the same algorithm; its -DORACLE_FAST build "
                 "moves literals and self-copies 16 bytes at a time as Snappier's SIMD path does (CopyHelpers.cs:64-230), and C++ snappy's decoder is the "
