@@ -133,7 +133,11 @@ struct snp_ctx {
             } else {
                 (void)hipGetLastError();
             }
-            if (!hint_seen && !hint_pending && hint_ready() && hipStreamQuery(stream) == hipSuccess) {
+            // (a stream that is being captured into a graph is never queried or synchronised: both would invalidate the capture)
+            hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(stream, &cap_st) != hipSuccess || cap_st != hipStreamCaptureStatusNone;
+            if (capturing) (void)hipGetLastError();
+            if (!hint_seen && !hint_pending && !capturing && hint_ready() && hipStreamQuery(stream) == hipSuccess) {
                 // The FIRST batch of a context has no previous batch to go by.  When its stream is idle (nothing queued that a wait would
                 // sit behind), a 10 us sample of this batch's capacities (k_sample_caps: <= 16 384 of them, strided) is read back at once:
                 // a first call of 64 KiB blocks then goes straight to one block per wavefront instead of the pre-pass + list kernel (12.10 vs
