@@ -8,7 +8,8 @@ SNAPPIER_HIP_LIB=...; SNAPPIER_HIP_CL_ABLATE is read per launch).  What owns the
   32  one more exchange + store per probe elsewhere in the lane's table (net effect none): time(32) - time(0) = cost of 1.63 G more
       random exchanges + 1.63 G more random stores
   64 / 128  the ip - 1 insert as a non-temporal / an agent-scope (sc1) store -- experiments, results unchanged
-Masks 0, 2, 8, 32, 64, 128 must produce the reference bytes (checked); 1 and 4 are wrong by construction.
+  256 / 512  the probe exchange at workgroup / wavefront scope instead of agent scope (the table is lane-private) -- experiments, results unchanged
+Masks 0, 2, 8, 32, 64, 128, 256, 512 must produce the reference bytes (checked); 1 and 4 are wrong by construction.
    python scripts/ab_compress_ablate.py [masks...]   DATA=html|mixed   ->  one JSON line"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -46,7 +47,7 @@ for rep in range(int(os.environ.get("REPS", "4"))):
         res[m].append(round(ms, 2))
         tot = int(out_len.to(torch.int64).sum().item())
         total[m] = tot
-        if m in (0, 2, 8, 32, 10, 34, 40, 42, 64, 128):
+        if m in (0, 2, 8, 32, 10, 34, 40, 42, 64, 128, 256, 512):
             crcs = cd.crc32c(comp, comp_off, out_len)
             sig = (tot, int(crcs.to(torch.int64).sum().item()))
             ref = sig if ref is None else ref
