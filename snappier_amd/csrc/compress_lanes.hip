@@ -434,6 +434,17 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 // one probe per trip and it is always inserted when legal (:333 / :397), so read + insert is one exchange; a probe into
                 // the bucket the ip - 1 insert of this same trip just wrote takes that entry from the register instead
                 swapped = legal[0] && h[0] != hm1;
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x1c0000)) {     // (experiments 1024 / 2048 / 4096: the exchange through inline asm with cache-policy bits: sc0 | sc0 nt | sc0 sc1)
+                    const u32 nv = p[0] | check_bits(d[0]);
+                    u32 old = vm1;
+                    if (legal[0] && swapped) {
+                        u32* const ap = &c.table[h[0]];
+                        if (lit_blind & 0x40000) asm volatile("global_atomic_swap %0, %1, %2, off sc0\n s_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ap), "v"(nv) : "memory");
+                        else if (lit_blind & 0x80000) asm volatile("global_atomic_swap %0, %1, %2, off sc0 nt\n s_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ap), "v"(nv) : "memory");
+                        else asm volatile("global_atomic_swap %0, %1, %2, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ap), "v"(nv) : "memory");
+                    }
+                    cv[0] = !legal[0] ? 0u : old;
+                } else
                 if (SNP_CL_ABLATE_RT && (lit_blind & 0x30000)) {      // (experiments 256 / 512: the exchange at workgroup / wavefront scope -- the table is lane-private, any scope is correct)
                     const u32 nv = p[0] | check_bits(d[0]);
                     cv[0] = !legal[0] ? 0u : !swapped ? vm1
@@ -754,7 +765,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
     // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
     const char* ab = getenv("SNAPPIER_HIP_CL_ABLATE");              // (acts in -DSNP_CL_ABLATE_RT=1 builds only: timing-only ablations, bits 8.. of the option word)
-    const int lit_blind = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0))) | ((SNP_CL_ABLATE_RT && ab) ? (atoi(ab) & 1023) << 8 : 0);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
+    const int lit_blind = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0))) | ((SNP_CL_ABLATE_RT && ab) ? (atoi(ab) & 8191) << 8 : 0);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
