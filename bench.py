@@ -252,15 +252,28 @@ def cpu_baseline(raw_sample: np.ndarray, variant: int):
     }
 
 
+def pmc_rows(directory: str, counter: str) -> dict:
+    """{kernel: [bytes of `counter` per dispatch]} from the *counter_collection.csv files rocprofv3 --pmc left under `directory` (one row per
+    dispatch and counter; FETCH_SIZE / WRITE_SIZE are in KB).  Only the codec kernels' full-size launches (>= 64 wavefronts)."""
+    import csv
+    import glob
+    import re
+    per = {}
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                m = re.search(r"(k_(?:compress|decompress)[a-z_0-9]*)", r["Kernel_Name"])
+                if m and r["Counter_Name"] == counter and int(r["Grid_Size"]) >= 64 * 64:      # (not the few-wavefront helpers)
+                    per.setdefault(m.group(1), []).append(float(r["Counter_Value"]) * 1024.0)
+    return per
+
+
 def live_traffic(nb: int, hash_name: str, config: int):
     """HBM traffic of the codec kernels MEASURED on this box in this bench invocation: two child runs of this script (one untimed setup pass +
     one step each) under `rocprofv3 --pmc`, ONE counter per pass (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md),
     no trace domains.  Returns {kernel: {"fetch_bytes", "write_bytes", "launches"}} per LAUNCH (mean over the launches of the child), or a string
     saying why it could not be measured (the line then falls back to the replayed profile and says so).  Counters are in KB; the calibration of
     profiles/r01k_pmc_calibration.json applies: scattered narrow accesses (both codec kernels) are counted exactly."""
-    import csv
-    import glob
-    import re
     import shutil
     tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(tool):
@@ -276,13 +289,7 @@ def live_traffic(nb: int, hash_name: str, config: int):
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=90, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         except Exception as e:                                  # noqa: BLE001
             return f"rocprofv3 --pmc {counter} pass failed: {type(e).__name__}"
-        per = {}
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            with open(f) as fh:
-                for r in csv.DictReader(fh):
-                    m = re.search(r"(k_(?:compress|decompress)[a-z_0-9]*)", r["Kernel_Name"])
-                    if m and r["Counter_Name"] == counter and int(r["Grid_Size"]) >= 64 * 64:      # (not the few-wavefront helpers)
-                        per.setdefault(m.group(1), []).append(float(r["Counter_Value"]) * 1024.0)
+        per = pmc_rows(d, counter)
         shutil.rmtree(d, ignore_errors=True)
         if not per:
             return f"rocprofv3 --pmc {counter} pass produced no rows for the codec kernels"
