@@ -12,6 +12,7 @@ import snappier_amd as S
 html = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "testdata", "html"), "rb").read()
 ctx = S.Context(0, S.HASH_CRC32C)
 L = S.lib()
+pinned = os.environ.get("PINNED", "0") == "1"
 sizes = [int(a) for a in sys.argv[1:]] or [65536, 1 << 20, 16 << 20, 256 << 20, 1 << 30]
 vp = lambda a: C.c_void_p(a.ctypes.data)   # noqa: E731
 for n in sizes:
@@ -21,9 +22,14 @@ for n in sizes:
         rng = np.random.default_rng(7)
         idx = rng.integers(0, n, n // 100)
         data[idx] = rng.integers(0, 256, idx.size, dtype=np.uint8)
-    comp = np.empty(L.snp_max_compressed_length(n), dtype=np.uint8)
-    framed = np.empty(L.snp_frame_max_encoded_length(n), dtype=np.uint8)
-    back = np.empty(n, dtype=np.uint8)
+    if pinned:                             # page-locked buffers (hipHostMalloc through torch): what snp_host_alloc hands a caller
+        hold = [torch.empty(k, dtype=torch.uint8).pin_memory() for k in (n, L.snp_max_compressed_length(n), L.snp_frame_max_encoded_length(n), n)]
+        hold[0].numpy()[:] = data
+        data, comp, framed, back = (t.numpy() for t in hold)
+    else:
+        comp = np.empty(L.snp_max_compressed_length(n), dtype=np.uint8)
+        framed = np.empty(L.snp_frame_max_encoded_length(n), dtype=np.uint8)
+        back = np.empty(n, dtype=np.uint8)
     w = C.c_size_t(0)
 
     def call(fn, src, sn, dst):
@@ -43,7 +49,7 @@ for n in sizes:
     t_fe, wf = best(lambda: call(L.snp_frame_encode, data, n, framed), 2)
     t_fd, wb = best(lambda: call(L.snp_frame_decode, framed, wf, back), 2)
     assert wb == n and np.array_equal(back, data)
-    print(json.dumps({"bytes": n, "ratio": round(wc / n, 4), 
+    print(json.dumps({"bytes": n, "host_buffers": "pinned" if pinned else "pageable", "ratio": round(wc / n, 4), 
                       "compress_ms": round(t_c * 1e3, 3), "compress_GBps": round(n / t_c / 1e9, 3),
                       "decompress_ms": round(t_d * 1e3, 3), "decompress_GBps": round(n / t_d / 1e9, 3),
                       "frame_encode_GBps": round(n / t_fe / 1e9, 3), "frame_decode_GBps": round(n / t_fd / 1e9, 3)}), flush=True)
