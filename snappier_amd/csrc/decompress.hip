@@ -263,6 +263,9 @@ __device__ __forceinline__ void lanes_sync_lds() { asm volatile("" ::: "memory")
 #define SNP_D_PF 1          // sub-chain front end: request the next batch's tag bytes while this batch executes
 #endif
 #ifndef SNP_D_PASSES
+#ifndef SNP_D_P2MIN
+#define SNP_D_P2MIN 2     // FRONT 3: the second lane-parallel pass runs only for batches with at least this many pending tags
+#endif
 #define SNP_D_PASSES 1      // queued mode: extra lane-parallel passes over pending tags before the serial finish
 #endif
 #ifndef SNP_D_RING
@@ -1122,7 +1125,8 @@ __device__ __forceinline__ void decompress_block(const u8* __restrict__ in, cons
                 // second lane-parallel pass: sources inside the batch that no pending tag still has to write
                 bool blocked = off < len || s_lo < mark;                // pattern copies and sources straddling `mark`: finished in order
                 const bool mine = (pend >> lane) & 1ull;
-                if ((SNP_D_ABLATE & 16) == 0 && (pend & (pend - 1))) {
+                if (SNP_D_P2MIN > 2 && (pend & (pend - 1)) != 0 && static_cast<u32>(__builtin_popcountll(pend)) < SNP_D_P2MIN) blocked = true;   // too few for a pass of their own
+                else if ((SNP_D_ABLATE & 16) == 0 && (pend & (pend - 1))) {
                     c_busy[lane] = 0ull;
                     lanes_sync_lds();
                     if (mine) {
