@@ -248,3 +248,86 @@ def test_fuzz_corrupted_big_blocks_match_the_oracle(ctx):
             assert got == want, (i, got, want, cap)
             bad_seen += 1
     assert ok_seen and bad_seen
+
+
+def test_single_block_of_int_max_bytes_matches_oracle():
+    """The reference's largest span: ONE block of int.MaxValue bytes (2 GiB - 1) through snp_try_compress / snp_try_decompress -- 32 768 fragments
+    behind one varint, offsets inside the block up to 2^31 - 1: bytes equal to the oracle's, and back.  One byte more is outside the reference's
+    domain ((int)length goes negative, SnappyDecompressor.cs:129,160): the oracle and the library both answer "invalid stream length"."""
+    import ctypes as C
+    import psutil
+    if psutil.virtual_memory().available < (20 << 30):
+        pytest.skip("needs ~10 GiB of host memory")
+    n = 0x7fffffff
+    tile = np.frombuffer(corpus_bytes(24 << 20), dtype=np.uint8)
+    data = np.tile(tile, n // tile.size + 1)[:n].copy()
+    rng = np.random.default_rng(2031)
+    idx = rng.integers(0, n, n // 300)
+    data[idx] = rng.integers(0, 256, idx.size, dtype=np.uint8)             # the repeats of the tile differ
+    L = S.lib()
+    ctx = S.Context(0, O.HASH_CRC32C)
+    assert L.snp_max_compressed_length(n) == -1                             # Snappy.GetMaxCompressedLength overflows int there (Helpers.cs:17-49) ...
+    n_ref = 1840700237                                                      # ... its own largest argument: 32 + n + n / 6 + 1 + 5 == int.MaxValue
+    assert L.snp_max_compressed_length(n_ref) == 0x7fffffff and L.snp_max_compressed_length(n_ref + 1) == -1
+    cap = 0x7fffffff                                                        # the largest output span there is; enough for this data
+    comp = np.empty(cap, dtype=np.uint8)
+    w = C.c_size_t(0)
+    assert L.snp_try_compress(ctx.handle, data.ctypes.data, n, comp.ctypes.data, cap, C.byref(w)) == 0
+    exp = np.empty(cap, dtype=np.uint8)
+    we = C.c_size_t(0)
+    assert O.lib().orc_compress(data.ctypes.data, n, exp.ctypes.data, cap, O.HASH_CRC32C, C.byref(we)) == 0
+    assert w.value == we.value and w.value > (1 << 29)
+    assert np.array_equal(comp[: w.value], exp[: we.value])
+    del exp
+    ln, hdr = C.c_uint32(0), C.c_uint32(0)
+    assert L.snp_get_uncompressed_length(comp.ctypes.data, w.value, C.byref(ln), C.byref(hdr)) == 0 and ln.value == n and hdr.value == 5
+    back = np.zeros(n, dtype=np.uint8)
+    wb = C.c_size_t(0)
+    assert L.snp_try_decompress(ctx.handle, comp.ctypes.data, w.value, back.ctypes.data, n, C.byref(wb)) == 0 and wb.value == n
+    assert np.array_equal(back, data)
+    assert ctx.counter(0) == 1                                               # decoded by fragments (tag index), not by one wavefront
+    # one byte short of room: the reference's "output too small"
+    assert L.snp_try_decompress(ctx.handle, comp.ctypes.data, w.value, back.ctypes.data, n - 1, C.byref(wb)) == O.ERR_OUTPUT_TOO_SMALL
+    # a declared length of 2^31: outside the reference's domain -- same answer as the oracle, whatever the room
+    beyond = varint(1 << 31) + literal(b"abcdefgh")
+    with pytest.raises(O.OracleError) as e:
+        O.decompress(beyond, cap=16)
+    assert e.value.status == O.ERR_BAD_LENGTH
+    src = np.frombuffer(beyond, dtype=np.uint8).copy()
+    assert L.snp_try_decompress(ctx.handle, src.ctypes.data, src.size, back.ctypes.data, n, C.byref(wb)) == O.ERR_BAD_LENGTH
+
+
+def test_framed_stream_beyond_4_gib_matches_oracle():
+    """A SnappyStream of 4 GiB + 197 385 bytes (65 540 chunks, the last one ragged; the corpus' jpeg makes some of them raw chunks) through
+    snp_frame_encode / snp_frame_decode: every byte position of the stream and of its framing beyond 2^32 for the tail -- the framed bytes equal
+    the oracle's (SnappyStreamCompressor.cs:194-261), and decode + CRC verification give the input back (SnappyStreamDecompressor.cs:38-208)."""
+    import ctypes as C
+    import psutil
+    if psutil.virtual_memory().available < (32 << 30):
+        pytest.skip("needs ~18 GiB of host memory")
+    n = (4 << 30) + 3 * 65536 + 777
+    tile = np.frombuffer(corpus_bytes(24 << 20), dtype=np.uint8)
+    data = np.tile(tile, n // tile.size + 1)[:n].copy()
+    rng = np.random.default_rng(4097)
+    idx = rng.integers(0, n, n // 300)
+    data[idx] = rng.integers(0, 256, idx.size, dtype=np.uint8)
+    L = S.lib()
+    ctx = S.Context(0, O.HASH_CRC32C)
+    cap = L.snp_frame_max_encoded_length(n)
+    assert cap == O.lib().orc_frame_max_encoded_length(n) and cap > n
+    framed = np.empty(cap, dtype=np.uint8)
+    w = C.c_size_t(0)
+    assert L.snp_frame_encode(ctx.handle, data.ctypes.data, n, framed.ctypes.data, cap, C.byref(w)) == 0
+    exp = np.empty(cap, dtype=np.uint8)
+    we = C.c_size_t(0)
+    assert O.lib().orc_frame_encode(data.ctypes.data, n, exp.ctypes.data, cap, O.HASH_CRC32C, C.byref(we)) == 0
+    assert w.value == we.value
+    assert np.array_equal(framed[: w.value], exp[: we.value])
+    del exp
+    back = np.zeros(n, dtype=np.uint8)
+    wb = C.c_size_t(0)
+    assert L.snp_frame_decode(ctx.handle, framed.ctypes.data, w.value, back.ctypes.data, n, C.byref(wb)) == 0 and wb.value == n
+    assert np.array_equal(back, data)
+    # a flipped payload byte beyond the 4 GiB mark is caught by that chunk's CRC (or its decoder) and nowhere else
+    framed[w.value - 1000] ^= 0x40
+    assert L.snp_frame_decode(ctx.handle, framed.ctypes.data, w.value, back.ctypes.data, n, C.byref(wb)) != 0
