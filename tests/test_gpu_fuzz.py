@@ -480,3 +480,63 @@ def test_small_fragment_launch_with_input_in_lds_equals_oracle(variant, monkeypa
         for limit in (256, 256):
             compared += check(batch(limit, 2000, exact=(per == "64")), f"{per} lanes per wavefront")
     log_session(test="small_fragment_launch_with_input_in_lds", hash_variant=variant, blocks_compared=compared, result="all equal")
+
+
+def _compare_batch(cd, data, off, lens, variant, what):
+    """Compress (tight output layout: every block gets exactly snp_max_compressed_length of its own length), compare every block with the oracle,
+    decompress the device's bytes back and compare with the input.  -> blocks compared."""
+    nb = len(lens)
+    caps = 32 + lens.astype(np.int64) + lens.astype(np.int64) // 6 + 1 + 5          # Snappy.GetMaxCompressedLength  Snappy.cs:20-24
+    c_off = np.zeros(nb, dtype=np.int64)
+    c_off[1:] = np.cumsum(caps[:-1])
+    out = torch.empty(int(caps.sum()) + 64, dtype=torch.uint8, device="cuda")
+    ref, ref_off, ref_len, ref_st = O.compress_batch(data, off.astype(np.uint64), lens.astype(np.uint32), variant, THREADS)
+    d_data, d_off, d_lens, d_coff = dev(data), dev(off), dev(lens), dev(c_off)
+    _o, _oo, out_len, status = cd.compress(d_data, d_off, d_lens, out=out, out_off=d_coff)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum()) == 0 and (ref_st == 0).all(), what
+    h_len = out_len.cpu().numpy()
+    assert (h_len == ref_len).all(), f"{what}: lengths differ at blocks {np.nonzero(h_len != ref_len)[0][:8]}"
+    h_out = out.cpu().numpy()
+    ro = ref_off.astype(np.int64)
+    for b in range(nb):
+        if not np.array_equal(h_out[c_off[b]: c_off[b] + h_len[b]], ref[ro[b]: ro[b] + h_len[b]]):
+            raise AssertionError(f"{what}: block {b} (len {lens[b]}) differs from the oracle")
+    back = torch.zeros(data.size, dtype=torch.uint8, device="cuda")
+    dlen, dst = cd.decompress(out, d_coff, out_len, back, d_off, d_lens)
+    torch.cuda.synchronize()
+    assert int((dst != 0).sum()) == 0 and bool((dlen == d_lens).all()), what
+    total = int(off[-1] + lens[-1])
+    assert bool(torch.equal(back[:total], d_data[:total])), what
+    return nb
+
+
+def test_batches_beyond_one_launch_slice_equal_oracle(monkeypatch):
+    """A lane-compressor batch of more than 262 144 fragments runs as several launches over one hash-table workspace (capi.hip, slice_fragments), and
+    the decoder's small-block pre-pass sees more blocks than any other test gives it: 600 000 blocks of 0..300 bytes in ONE call, every block equal to
+    the oracle and back.  Then the same seam at full fragment size: SNAPPIER_HIP_SLICE=4096 cuts 9 000 mixed fragments (up to 64 KiB) into three launches."""
+    text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt") + read_testdata("geo.protodata"), dtype=np.uint8)
+    rng = np.random.default_rng(262144)
+    nb = 600000
+    lens = rng.integers(0, 301, nb).astype(np.int32)
+    lens[rng.integers(0, nb, 2000)] = rng.choice(np.array([0, 1, 14, 15, 16, 17, 300], dtype=np.int32), 2000)
+    off = np.zeros(nb, dtype=np.int64)
+    off[1:] = np.cumsum(lens[:-1].astype(np.int64))
+    total = int(off[-1] + lens[-1])
+    data = np.resize(text, total + 64).copy()
+    k = total // 40
+    data[rng.integers(0, total, k)] = rng.integers(0, 256, k, dtype=np.uint8)        # no two windows of the text alike
+    compared = 0
+    for variant in (O.HASH_CRC32C, O.HASH_MUL):
+        cd = SB.BlockCodec(0, variant)
+        compared += _compare_batch(cd, data, off, lens, variant, f"600 000 small blocks in one call, hash {variant}")
+        assert cd.ctx.counter(2) >= 0
+    monkeypatch.setenv("SNAPPIER_HIP_SLICE", "4096")
+    monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", "lanes")
+    monkeypatch.setenv("SNAPPIER_HIP_TABLE_TRIES", "1")
+    rng = np.random.default_rng(4096)
+    blocks = [make_block(rng, text) for _ in range(9000)]
+    d2, o2, l2 = batch_of(blocks)
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    compared += _compare_batch(cd, d2, o2, l2, O.HASH_CRC32C, "9 000 mixed fragments in slices of 4 096")
+    log_session(test="batches_beyond_one_launch_slice", blocks_compared=compared, result="all equal, and back")
