@@ -189,6 +189,12 @@ snp_status snp_frame_decode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* 
 
 /* ---- batch, device pointers (the hot path; asynchronous on the context's stream) ------------------------ */
 
+/* Stream capture: snp_compress_batch, snp_decompress_batch, snp_crc32c_batch and snp_frame_encode_device only enqueue kernels, so they may be called while the context's
+ * stream is being captured into a hipGraph and replayed later (the graph reads the device arrays as they are at replay time).  A captured call
+ * queries, synchronises and allocates nothing; it therefore needs the context's workspaces to exist already -- make the same call once before
+ * the capture (compress of >= 16 384 fragments: or snp_ctx_reserve_compress).  A call that would have to allocate during a capture returns
+ * SNP_ERR_DEVICE (snp_ctx_last_error says so) and leaves the capture valid.  The host-pointer entry points synchronise and cannot be captured. */
+
 /* nblocks independent inputs, each <= 65536 bytes (one fragment, SnappyCompressor.cs:40-80 loop body):
  * block b reads in[in_off[b] .. +in_len[b]) and writes  varint(in_len[b]) || CompressFragment  at
  * out[out_off[b] ..), which must have room for snp_max_compressed_length(in_len[b]) bytes.

@@ -120,7 +120,11 @@ struct snp_ctx {
             if (!ensure(redo, (static_cast<size_t>(sub_cap) * 64 + 128) * 4, "hipMalloc(redo list)")) return false;
             u32* const ctl = static_cast<u32*>(redo.p);                 // [0..63] sub-list lengths, [64] ticket, [65..67] size sample
             u32* const list = ctl + 128;
-            if (hint && hint_ev && hint_pending && hipEventQuery(hint_ev) == hipSuccess) {
+            // (a stream that is being captured into a graph is never queried or synchronised, and no event of this context is: all of that would
+            //  invalidate the capture.  A captured call goes by what the context knew before the capture began and leaves no hint behind.)
+            const bool capturing = stream_is_capturing();
+            if (capturing) {
+            } else if (hint && hint_ev && hint_pending && hipEventQuery(hint_ev) == hipSuccess) {
                 hint_pending = false;
                 if (hint_from_prepass) {
                     u64 left = 0;
@@ -133,16 +137,12 @@ struct snp_ctx {
             } else {
                 (void)hipGetLastError();
             }
-            // (a stream that is being captured into a graph is never queried or synchronised: both would invalidate the capture)
-            hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
-            const bool capturing = hipStreamIsCapturing(stream, &cap_st) != hipSuccess || cap_st != hipStreamCaptureStatusNone;
-            if (capturing) (void)hipGetLastError();
             if (!hint_seen && !hint_pending && !capturing && hint_ready() && hipStreamQuery(stream) == hipSuccess) {
                 // The FIRST batch of a context has no previous batch to go by.  When its stream is idle (nothing queued that a wait would
                 // sit behind), a 10 us sample of this batch's capacities (k_sample_caps: <= 16 384 of them, strided) is read back at once:
                 // a first call of 64 KiB blocks then goes straight to one block per wavefront instead of the pre-pass + list kernel (12.10 vs
                 // 11.55 ms per 10 GiB).  A busy stream keeps the old default (pre-pass): results are the same either way.
-                if (hipMemsetAsync(ctl, 0, 68 * 4, stream) == hipSuccess &&
+                if (snp_zero_words_async(ctl, 68, stream) == hipSuccess &&
                     snp_launch_sample_caps(out_cap, nblocks, small_max, ctl, stream) == hipSuccess &&
                     hipMemcpyAsync(hint, ctl, 68 * 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess && hint[67]) {
                     hint_mostly_large = static_cast<u64>(hint[65]) * 2 < hint[67];
@@ -151,11 +151,11 @@ struct snp_ctx {
                     (void)hipGetLastError();
                 }
             }
-            hint_seen = true;
+            if (!capturing) hint_seen = true;
             const bool chains = (fenced & 8) != 0;
             const bool pinned = small_lanes || small_team_log != 0;          // the caller chose the pre-pass layout: the previous batch is not asked
             const bool prepass = redo_list || !chains || pinned || (!redo_grid && !hint_mostly_large);
-            if (!check(hipMemsetAsync(ctl, 0, 68 * 4, stream), "memset(redo list)")) return false;
+            if (!check(snp_zero_words_async(ctl, 68, stream), "zero(redo list)")) return false;
             bool ok;
             if (prepass) {
                 // lanes per block and LDS per wavefront, by the mean block size of the previous batch (GB/s, profiles/r02t_small_block_layouts.jsonl
@@ -187,7 +187,7 @@ struct snp_ctx {
                                                  chunk_type, fenced | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch") &&
                      check(snp_launch_sample_caps(out_cap, nblocks, small_max, ctl, stream), "sample launch");
             }
-            if (ok && hint_ready() && !hint_pending) {                   // how this batch went, for the next one
+            if (ok && !capturing && hint_ready() && !hint_pending) {     // how this batch went, for the next one
                 hint_blocks = nblocks;
                 hint_from_prepass = prepass;
                 if (hipMemcpyAsync(hint, ctl, 68 * 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipEventRecord(hint_ev, stream) == hipSuccess)
@@ -199,6 +199,13 @@ struct snp_ctx {
         }
         return check(snp_launch_decompress(d_in, in_off, in_len, nblocks, d_out, out_off, out_cap, out_len, status,
                                            chunk_type, fenced | ((dec_lds / 256) << 8), stream, nullptr), "decompress launch");
+    }
+    bool stream_is_capturing()
+    {
+        hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(stream, &cap_st) != hipSuccess || cap_st != hipStreamCaptureStatusNone;
+        if (capturing) (void)hipGetLastError();
+        return capturing;
     }
     u32* hint = nullptr;                                 // pinned: the previous batch's list length
     hipEvent_t hint_ev = nullptr;
@@ -246,7 +253,9 @@ struct snp_ctx {
         }
         // 64 KiB of table per fragment in flight: very large batches (millions of small blocks) go in slices, so the
         // workspace stays <= 16 GiB; 262 144 fragments per launch still fill the chip many times over
-        if (chint && chint_ev && chint_pending && hipEventQuery(chint_ev) == hipSuccess) {
+        const bool capturing = stream_is_capturing();                   // (as in launch_decompress: a captured call neither reads nor leaves a hint)
+        if (capturing) {
+        } else if (chint && chint_ev && chint_pending && hipEventQuery(chint_ev) == hipSuccess) {
             chint_pending = false;
             chint_small = chint[0] != 0 && chint[0] <= 512;
             chint_mid = chint[0] != 0 && chint[0] <= 4096;
@@ -273,7 +282,7 @@ struct snp_ctx {
                        "compress (lanes) launch"))
                 return false;
         }
-        if (chint_ready() && !chint_pending) {                          // this batch's longest fragment, for the next one
+        if (!capturing && chint_ready() && !chint_pending) {            // this batch's longest fragment, for the next one
             if (hipMemcpyAsync(chint, small.p, 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipEventRecord(chint_ev, stream) == hipSuccess)
                 chint_pending = true;
             else
@@ -301,6 +310,10 @@ struct snp_ctx {
     bool ensure(DevBuf& b, size_t bytes, const char* what)
     {
         if (bytes <= b.cap) return true;
+        if (stream_is_capturing()) {                                    // hipFree / hipMalloc would invalidate the capture: refuse and leave it intact
+            err = std::string(what) + ": a workspace would have to grow while the stream is being captured -- make the same call once before the capture (or snp_ctx_reserve_compress)";
+            return false;
+        }
         if (b.p) (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
@@ -334,10 +347,12 @@ struct snp_ctx {
     bool ensure_tables(u32 nblocks, bool thorough = false)
     {
         const size_t bytes = snp_compress_lanes_workspace(nblocks);
-        if (!piece_mem.empty()) {
-            if (static_cast<uint64_t>(nblocks) <= static_cast<uint64_t>(tp.piece_frags) * tp.n) return true;
-            free_pieces();
+        if (!piece_mem.empty() && static_cast<uint64_t>(nblocks) <= static_cast<uint64_t>(tp.piece_frags) * tp.n) return true;
+        if ((!piece_mem.empty() || bytes > tables.cap) && stream_is_capturing()) {   // (as in ensure(): no allocation, no search, no synchronisation inside a capture)
+            err = "hash-table workspace: it would have to be built while the stream is being captured -- call snp_ctx_reserve_compress (or make the same call once) before the capture";
+            return false;
         }
+        if (!piece_mem.empty()) free_pieces();
         // The search inside a compress CALL is conservative unless the caller configured it: two workspaces' worth of candidates (one
         // transient extra workspace, a few hundred ms) -- a request must not take seconds or crowd a shared device.  The thorough
         // search (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, default 16) belongs to snp_ctx_reserve_compress, a service's start-up.

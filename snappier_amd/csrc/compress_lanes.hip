@@ -740,7 +740,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
                                                 int emit_varint, const snp_table_pieces* tables, u32* max_len, hipStream_t stream, int lanes_per_wave)
 {
     if (nblocks == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(max_len, 0, sizeof(u32), stream);
+    hipError_t e = snp_zero_words_async(max_len, 1, stream);
     if (e != hipSuccess) return e;
     const u32 mgrid = (nblocks + 255) / 256 < 1024 ? (nblocks + 255) / 256 : 1024u;
     hipLaunchKernelGGL(k_max_len, dim3(mgrid), dim3(256), 0, stream, in_len, nblocks, max_len);

@@ -61,3 +61,17 @@ __device__ __forceinline__ void wave_copy(u8* dst, const u8* src, u32 len, u32 l
 
 // Framing mask  Crc32CAlgorithm.ApplyMask  (Snappier/Internal/Crc32CAlgorithm.cs:156-158)
 __host__ __device__ __forceinline__ u32 crc32c_mask(u32 x) { return ((x >> 15) | (x << 17)) + 0xa282ead8u; }
+
+// A few control words set to zero ON THE STREAM.  Not hipMemsetAsync: as a node of a captured hipGraph a 4-byte memset runs on the first launch of the
+// graph only (ROCm 7.0, scripts/probe_graph_memset.py), and the batch entry points are meant to be capturable (tests/test_gpu_graph_capture.py).
+namespace {
+__global__ void k_zero_words(u32* p, u32 n)
+{
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+}  // namespace
+static inline hipError_t snp_zero_words_async(u32* p, u32 n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, p, n);
+    return hipGetLastError();
+}
