@@ -1019,3 +1019,28 @@ def test_full_size_config4_framing_roundtrip(codec):
     torch.cuda.synchronize()
     assert result.cpu().tolist()[1] != 0
 
+
+
+def test_frame_decode_takes_chunks_beyond_64_kib_like_the_reference():
+    """The framing format caps a chunk's uncompressed data at 65 536 bytes, but SnappyStreamDecompressor does not enforce it (it feeds whatever the
+    chunk holds to the block decompressor, SnappyStreamDecompressor.cs:90-157): a foreign stream with a 200 000-byte compressed chunk, a 200 000-byte
+    raw chunk or a chunk of 65 537 bytes decodes -- same bytes as the oracle through the host API and through the device-side header walk."""
+    def chunk(t, body):
+        return bytes([t]) + len(body).to_bytes(3, "little") + body
+
+    data = (read_testdata("alice29.txt") + read_testdata("html"))[:200000]
+    ident = O.frame_encode(b"x")[:10]
+    tail = b"tail" * 10
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    for n, typ in ((200000, 0), (200000, 1), (65537, 0), (70000, 1)):
+        raw = data[:n]
+        body = struct.pack("<I", O.crc32c(raw, masked=True)) + (O.compress(raw) if typ == 0 else raw)
+        stream = ident + chunk(typ, body) + chunk(0, struct.pack("<I", O.crc32c(tail, masked=True)) + O.compress(tail))
+        ref = O.frame_decode(stream)
+        assert ref == raw + tail
+        assert_same(f"host frame decode, chunk of {n} ({'compressed' if typ == 0 else 'raw'})", S.frame_decode(stream), ref)
+        out = torch.zeros(len(ref) + 64, dtype=torch.uint8, device="cuda")
+        res = cd.frame_decode(to_dev(np.frombuffer(stream, dtype=np.uint8).copy()), len(stream), out, 16)
+        torch.cuda.synchronize()
+        assert res.tolist() == [len(ref), 0]
+        assert_same("device header walk", out[: len(ref)].cpu().numpy().tobytes(), ref)
