@@ -46,6 +46,7 @@ struct PieceSearch {
     float lo = 0;                                // pair level of two pieces that share nothing
     u32 trials = 0;
     static constexpr float kSameOverDisjoint = 1.18f;   // 4.33 / 3.67
+    static constexpr float kOneSided = 0.965f;          // alone: one kind 3.93 ms, a 60 : 40 piece 3.65, an even one 3.38-3.58
     size_t patience = 6;                                // rounds of n candidates spent looking for a THIRD kind once two are balanced (three kinds: 30.3 ms per 4096 probes, two: 31.9;
                                                         // snp_ctx_reserve_compress, which runs when the caller has time, raises it to whatever max_cand allows)
 
@@ -97,12 +98,19 @@ struct PieceSearch {
         }
         if (unexplained.empty()) return false;
         std::sort(unexplained.begin(), unexplained.end());
-        u32 pick = unexplained[0].second;
-        for (size_t i = 1; i < unexplained.size() && i < 3; ++i)   // ... preferring a one-sided piece among the three least explained
-            if (alone_ms(unexplained[i].second) > alone_ms(pick)) pick = unexplained[i].second;
-        refs.push_back(pick);
-        pair_ms.emplace_back();
-        return true;
+        // A reference must be ONE-SIDED (all of one kind: probed alone it is as slow as the slowest piece seen, 3.93 against 3.38-3.65 ms for a piece that
+        // lies across kinds).  A third of device memory is such mixed pieces; no reference explains them, and as references they "explain" nothing either:
+        // a first round of them ended the search at 16-32 candidates with "4 references, largest share 0.30" and a workspace that ran at the two-kind
+        // level (GPU, round 4: profiles/r04ae_search_mixed_first_round.txt; tests/abi/piece_search_model.cpp "mixed pieces first").
+        float top = 0;
+        for (u32 k = 0; k < ncand; ++k) top = std::max(top, alone[k]);
+        for (const auto& u : unexplained)
+            if (alone_ms(u.second) >= kOneSided * top) {
+                refs.push_back(u.second);
+                pair_ms.emplace_back();
+                return true;
+            }
+        return false;
     }
     float choose(std::vector<u32>& set)          // n candidates with the smallest largest per-kind sum; returns that kind's share of the set
     {

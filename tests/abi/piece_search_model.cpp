@@ -92,6 +92,19 @@ int main()
     g_contrast = 1.0f;
     // everything straddles (balanced pieces alone)
     scenario("all pieces balanced", runs({{0, 1}, {-1, 60}, {1, 1}}), 256);
+    // a process whose first rounds are mostly MIXED pieces (each lies across two kinds, 60 : 40 or so -- the "F" pieces of the memory map, a third of device
+    // memory): no reference explains them, but they are not kinds of their own.  Seen on the GPU in round 4 (profiles/r04ae_search_mixed_first_round.txt):
+    // a search that made references of them stopped after 16-32 candidates with "4 references, largest share 0.30" and a workspace 6 % slower than
+    // the one a longer search finds.
+    {
+        std::vector<Shares> v;
+        const Shares mixes[6] = {{0.6f, 0.4f, 0.f}, {0.4f, 0.6f, 0.f}, {0.65f, 0.35f, 0.f}, {0.35f, 0.65f, 0.f}, {0.55f, 0.45f, 0.f}, {0.45f, 0.55f, 0.f}};
+        v.push_back(Shares{1.f, 0.f, 0.f});
+        v.push_back(Shares{1.f, 0.f, 0.f});
+        for (int i = 0; i < 30; ++i) v.push_back(mixes[i % 6]);
+        for (const Shares& x : runs({{1, 60}, {-1, 2}, {0, 30}, {-1, 2}, {2, 100}})) v.push_back(x);
+        scenario("mixed pieces first", v, 216, ~size_t(0), 64);
+    }
     // no room for spare candidates: the workspace is what could be allocated
     scenario("no spare candidates", runs({{0, 300}}), 16);
     // out of memory: before the workspace is complete / after one round

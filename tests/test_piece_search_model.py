@@ -24,7 +24,7 @@ def scenarios(tmp_path_factory):
 
 
 def test_every_scenario_ran_and_picks_sixteen_distinct_candidates(scenarios):
-    assert len(scenarios) == 10
+    assert len(scenarios) == 11
     for name, r in scenarios.items():
         assert r["distinct"] and r["in_range"], name
         if name != "out of memory at 10":
@@ -57,6 +57,13 @@ def test_the_search_goes_on_while_it_has_seen_one_kind_only(scenarios):
     assert 112 <= r["candidates"] <= 144 and r["largest_share"] <= 0.56
     r = scenarios["one kind only"]
     assert r["candidates"] == 64 and r["largest_share"] == 1.0            # its limit; nothing better exists
+
+
+def test_mixed_pieces_do_not_become_references(scenarios):
+    """Round 4 on the GPU: a first round of pieces that lie across two kinds made four "references" of them and ended the search at once with a
+    workspace at the two-kind level.  Only one-sided pieces may be references: the search goes on until the pure runs show up and ends on three kinds."""
+    r = scenarios["mixed pieces first"]
+    assert r["references"] == 3 and r["largest_share"] <= 0.45 and r["candidates"] >= 96
 
 
 def test_pieces_that_are_balanced_by_themselves_are_enough(scenarios):
