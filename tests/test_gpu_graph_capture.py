@@ -150,3 +150,36 @@ def test_device_resident_framing_replays_from_a_graph():
         res = cd.frame_decode(framed, w, back, nb + 8, work=work_d)
         torch.cuda.synchronize()
         assert res.tolist() == [n, 0] and torch.equal(back, contents)
+
+
+@pytest.mark.parametrize("nb", [64, 4096])
+def test_capture_on_a_stream_the_context_has_not_seen(nb):
+    """The context was only ever used on the default stream; torch's own capture stream meets it inside the capture (snp_ctx_set_stream: the new
+    stream waits for what the old one still has queued -- an event recorded outside the capture).  Replays and later direct calls are right."""
+    html = read_testdata("html")
+    cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    raw = SD.html_like_blocks(html, 0, nb, "cuda")
+    in_off, in_len = cd.uniform_layout(nb)
+    comp = torch.empty(nb * cd.comp_stride, dtype=torch.uint8, device="cuda")
+    comp_off = torch.arange(nb, dtype=torch.int64, device="cuda") * cd.comp_stride
+    back = torch.zeros_like(raw)
+
+    def pair():
+        _, _, out_len, st = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
+        return cd.decompress(comp, comp_off, out_len, back, in_off, in_len)
+
+    pair()
+    pair()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        dlen, dst = pair()
+    for _ in range(3):
+        back.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert int((dst != 0).sum()) == 0 and torch.equal(back, raw)
+    back.zero_()
+    pair()
+    torch.cuda.synchronize()
+    assert torch.equal(back, raw)
