@@ -3,4 +3,4 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 rm -f gpurun_out/fuzz_log.jsonl
-FUZZ_ROUNDS=${FUZZ_ROUNDS:-40} FUZZ_BLOCKS=${FUZZ_BLOCKS:-2048} timeout ${FUZZ_TIMEOUT:-1500} python -m pytest tests/test_gpu_fuzz.py -m gpu -q -p no:cacheprovider 2>&1 | tail -15 | tee gpurun_out/fuzz_parity.log
+FUZZ_SEED=${FUZZ_SEED:-0} FUZZ_ROUNDS=${FUZZ_ROUNDS:-40} FUZZ_BLOCKS=${FUZZ_BLOCKS:-2048} timeout ${FUZZ_TIMEOUT:-1500} python -m pytest tests/test_gpu_fuzz.py -m gpu -q -p no:cacheprovider 2>&1 | tail -15 | tee gpurun_out/fuzz_parity.log

@@ -21,6 +21,7 @@ if torch.cuda.is_available():
 
 ROUNDS = int(os.environ.get("FUZZ_ROUNDS", "2"))
 BLOCKS = int(os.environ.get("FUZZ_BLOCKS", "768"))
+SEED0 = int(os.environ.get("FUZZ_SEED", "0")) * 1000003             # FUZZ_SEED=k: the same tests on other inputs (a long session per k)
 THREADS = min(os.cpu_count() or 1, 64)
 EDGE_LENGTHS = [0, 1, 3, 4, 14, 15, 16, 17, 18, 19, 31, 32, 60, 61, 64, 65, 255, 256, 257, 4095, 4096, 16383, 16384, 16385,
                 32768, 65520, 65521, 65535, 65536]
@@ -102,7 +103,7 @@ def test_fuzz_compress_bytes_equal_oracle(layout, variant, monkeypatch):
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
     cd = SB.BlockCodec(0, variant)
     for r in range(ROUNDS):
-        rng = np.random.default_rng(1000 * r + 17 * variant + (layout == "lanes"))
+        rng = np.random.default_rng(SEED0 + 1000 * r + 17 * variant + (layout == "lanes"))
         blocks = [make_block(rng, text) for _ in range(BLOCKS)]
         data, off, lens = batch_of(blocks)
         ref, ref_off, ref_len, ref_st = O.compress_batch(data, off.astype(np.uint64), lens.astype(np.uint32), variant, THREADS)
@@ -116,7 +117,7 @@ def test_fuzz_compress_bytes_equal_oracle(layout, variant, monkeypatch):
             want = ref[int(ref_off[b]): int(ref_off[b]) + int(ref_len[b])]
             assert np.array_equal(got, want), f"round {r} block {b} (len {lens[b]}) {layout} v{variant}"
     log_session(test="compress_bytes_equal_oracle", layout=layout, hash_variant=variant, rounds=ROUNDS, blocks_per_round=BLOCKS,
-                blocks_compared=ROUNDS * BLOCKS, seeds=[1000 * r + 17 * variant + (layout == "lanes") for r in range(ROUNDS)], result="all equal")
+                blocks_compared=ROUNDS * BLOCKS, seeds=[SEED0 + 1000 * r + 17 * variant + (layout == "lanes") for r in range(ROUNDS)], result="all equal")
 
 
 def corrupt(rng: np.random.Generator, z: np.ndarray) -> np.ndarray:
@@ -158,7 +159,7 @@ def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatc
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
     for r in range(ROUNDS):
-        rng = np.random.default_rng(777 + r)
+        rng = np.random.default_rng(SEED0 + 777 + r)
         blocks = [make_block(rng, text) for _ in range(BLOCKS)]
         data, off, lens = batch_of(blocks)
         comp, c_off, c_len, _ = O.compress_batch(data, off.astype(np.uint64), lens.astype(np.uint32), O.HASH_CRC32C, THREADS)
@@ -183,7 +184,7 @@ def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatc
             assert np.array_equal(out[out_off[b]: out_off[b] + dlen[b]], ref[out_off[b]: out_off[b] + ref_len[b]]), f"round {r} block {b}"
         assert ok.size > BLOCKS // 10 and ok.size < BLOCKS    # the corruptions produce both outcomes
     log_session(test="corrupted_streams_status_and_bytes_equal_oracle", decode=decode, rounds=ROUNDS, blocks_per_round=BLOCKS,
-                blocks_compared=ROUNDS * BLOCKS, seeds=[777 + r for r in range(ROUNDS)], result="all statuses and bytes equal")
+                blocks_compared=ROUNDS * BLOCKS, seeds=[SEED0 + 777 + r for r in range(ROUNDS)], result="all statuses and bytes equal")
 
 
 @pytest.mark.parametrize("layout", ["lanes", "team4", "team8", "team16"])
@@ -199,7 +200,7 @@ def test_fuzz_small_blocks_corrupted_streams_equal_oracle(layout, monkeypatch):
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
     nb = 4 * BLOCKS
     for r in range(ROUNDS):
-        rng = np.random.default_rng(4242 + r)
+        rng = np.random.default_rng(SEED0 + 4242 + r)
         blocks = []
         for _ in range(nb):
             n = int(rng.integers(1, 513))
@@ -237,7 +238,7 @@ def test_fuzz_small_blocks_corrupted_streams_equal_oracle(layout, monkeypatch):
         assert np.array_equal(out[idx], ref[idx]), f"round {r} {layout}: bytes differ"
         assert ok.size > nb // 10 and ok.size < nb
     log_session(test="small_blocks_corrupted_streams_equal_oracle", layout=layout, rounds=ROUNDS, blocks_per_round=nb,
-                blocks_compared=ROUNDS * nb, seeds=[4242 + r for r in range(ROUNDS)], result="all statuses, lengths and bytes equal")
+                blocks_compared=ROUNDS * nb, seeds=[SEED0 + 4242 + r for r in range(ROUNDS)], result="all statuses, lengths and bytes equal")
 
 
 TAXONOMY = [
