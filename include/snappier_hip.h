@@ -126,8 +126,9 @@ typedef enum snp_option {
     SNP_OPT_PARALLEL_DECODE_MIN = 8,    /* snp_try_decompress: declared bytes from which ONE block is decoded a wavefront per 64 KiB fragment (0 = never; default 262144) */
     SNP_OPT_FENCED = 9,                 /* 1 (default): a wavefront drains its stores before it reads output bytes it wrote itself; 0 relies on in-order vector memory */
     SNP_OPT_DECODE_LEFTOVERS = 10,      /* blocks the pre-pass leaves over: 0 (default) by the previous batch, 1 one workgroup per block, 2 a list for persistent wavefronts */
-    /* CRC-32C kernel: 0 (default) the GF(2) shift map sliced by 8 out of four 256-entry tables in LDS (4.5-5.3 TB/s); 1 = TABLE-FREE, the
-     * map applied bit by bit in registers (1.7 TB/s: VALU-bound; gfx950 has neither a CRC instruction nor a carry-less multiply). */
+    /* CRC-32C kernel: 0 (default) the GF(2) shift map sliced 11 + 11 + 10 bits out of three tables in LDS (5.8 TB/s); 1 = TABLE-FREE, the
+     * map applied bit by bit in registers (1.7 TB/s: VALU-bound; gfx950 has neither a CRC instruction nor a carry-less multiply);
+     * 2 = round 3's four 256-entry tables (5.3 TB/s).  Same results. */
     SNP_OPT_CRC_TABLE_FREE = 11
 } snp_option;
 snp_status snp_ctx_set_option(snp_ctx* ctx, int option, int64_t value);

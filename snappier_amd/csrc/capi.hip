@@ -85,7 +85,8 @@ struct snp_ctx {
                              // a team of lanes per block, out of LDS); 0 = never.  Above 512 bytes the wave kernel is faster (768-1024 B:
                              // teams 180-260 GB/s, wave kernel 280-335; profiles/r02t_team_budget.jsonl).
     u32 small_min_blocks = 4096;   // ... in batches of at least this many blocks
-    bool crc_table_free = false;   // SNP_OPT_CRC_TABLE_FREE: the table-free CRC-32C kernel (1.7 TB/s) instead of the LDS-table one (4.5-5.3 TB/s)
+    int crc_kernel = 0;            // SNP_OPT_CRC_TABLE_FREE: 0 = three LDS tables of 11 + 11 + 10 bits (default), 1 = the table-free kernel (1.7 TB/s), 2 = four 8-bit tables (round 3)
+    int crc_bits() const { return crc_kernel == 1 ? 2 : crc_kernel == 2 ? 4 : 0; }
     bool no_prepass = false;       // SNP_OPT_DECODE_LAYOUT = 1: every block by the one-block-per-wavefront kernel
     bool small_lanes = false;      // SNAPPIER_HIP_SMALL=lanes: the block-per-lane kernel instead of a team of lanes per block
     bool redo_grid = false, redo_list = false;   // SNAPPIER_HIP_REDO=grid|list pins how the pre-pass's leftovers are decoded (default: by how the previous batch went)
@@ -627,8 +628,8 @@ snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
             c->redo_list = v == 2;
             return SNP_OK;
         case SNP_OPT_CRC_TABLE_FREE:
-            if (v != 0 && v != 1) return SNP_ERR_BAD_ARG;
-            c->crc_table_free = v == 1;
+            if (v < 0 || v > 2) return SNP_ERR_BAD_ARG;
+            c->crc_kernel = static_cast<int>(v);
             return SNP_OK;
         default:
             return SNP_ERR_BAD_ARG;
@@ -649,7 +650,7 @@ snp_status snp_ctx_get_option(const snp_ctx* c, int option, int64_t* out)
         case SNP_OPT_PARALLEL_DECODE_MIN: *out = c->par_min; return SNP_OK;
         case SNP_OPT_FENCED: *out = c->fenced & 1; return SNP_OK;
         case SNP_OPT_DECODE_LEFTOVERS: *out = c->redo_grid ? 1 : c->redo_list ? 2 : 0; return SNP_OK;
-        case SNP_OPT_CRC_TABLE_FREE: *out = c->crc_table_free ? 1 : 0; return SNP_OK;
+        case SNP_OPT_CRC_TABLE_FREE: *out = c->crc_kernel; return SNP_OK;
         default: return SNP_ERR_BAD_ARG;
     }
 }
@@ -805,7 +806,7 @@ snp_status snp_crc32c_batch(snp_ctx* c, const uint8_t* in, const uint64_t* in_of
     if (!c || (nblocks && (!in || !in_off || !in_len || !out_crc))) return SNP_ERR_BAD_ARG;
     DevGuard dg(c);
     if (!dg.ok) return SNP_ERR_DEVICE;
-    return c->check(snp_launch_crc32c(in, in_off, in_len, nblocks, (masked ? 1 : 0) | (c->crc_table_free ? 2 : 0), out_crc, nullptr, nullptr, c->stream),
+    return c->check(snp_launch_crc32c(in, in_off, in_len, nblocks, (masked ? 1 : 0) | c->crc_bits(), out_crc, nullptr, nullptr, c->stream),
                     "crc32c launch") ? SNP_OK : SNP_ERR_DEVICE;
 }
 
@@ -856,7 +857,7 @@ static snp_status frame_encode_impl(snp_ctx* c, const uint8_t* d_in, const uint8
     if (host_in) ok = ok && c->upload_and_compress(host_in, n, nc, w.in_off, w.in_len, w.comp, w.comp_off, w.comp_len, w.status, 1);
     else ok = ok && c->launch_compress(d_in, w.in_off, w.in_len, nc, w.comp, w.comp_off, w.comp_len, w.status, 1);
     // masked CRC-32C of the RAW chunk  (:243-245,258-260)
-    ok = ok && c->check(snp_launch_crc32c(d_in, w.in_off, w.in_len, nc, 1 | (c->crc_table_free ? 2 : 0), w.crc, nullptr, nullptr, s), "frame crc");
+    ok = ok && c->check(snp_launch_crc32c(d_in, w.in_off, w.in_len, nc, 1 | c->crc_bits(), w.crc, nullptr, nullptr, s), "frame crc");
     ok = ok && c->check(snp_launch_frame_plan(w.in_len, w.comp_len, nc, w.type, w.payload, w.dst_off, d_written, s),
                         "frame plan");
     ok = ok && c->check(snp_launch_frame_emit(d_in, w.in_off, w.comp, w.comp_off, w.type, w.payload, w.crc, w.dst_off,
@@ -888,7 +889,7 @@ snp_status snp_frame_decode_chunks_device(snp_ctx* c, const uint8_t* d_in, const
     hipStream_t s = c->stream;
     bool ok = c->launch_decompress(d_in, body_off, body_len, nchunks, d_out, out_off, out_cap, out_len, status, chunk_type);
     // CRC over the produced bytes, compared with the chunk's stored masked CRC  (SnappyStreamDecompressor.cs:117-131)
-    ok = ok && c->check(snp_launch_crc32c(d_out, out_off, out_len, nchunks, 1 | (c->crc_table_free ? 2 : 0), nullptr, chunk_crc, status, s),
+    ok = ok && c->check(snp_launch_crc32c(d_out, out_off, out_len, nchunks, 1 | c->crc_bits(), nullptr, chunk_crc, status, s),
                         "frame crc verify");
     return ok ? SNP_OK : SNP_ERR_DEVICE;
 }
@@ -1198,7 +1199,7 @@ snp_status snp_crc32c(snp_ctx* c, const uint8_t* in, size_t n, int masked, uint3
     bool ok = c->check(hipMemcpyAsync(m, &h, sizeof(h), hipMemcpyHostToDevice, s), "H2D meta");
     if (n) ok = ok && c->h2d(c->in.p, in, n, "H2D input");
     ok = ok && c->check(snp_launch_crc32c(static_cast<const u8*>(c->in.p), reinterpret_cast<u64*>(m), reinterpret_cast<u32*>(m + 8),
-                                          1, (masked ? 1 : 0) | (c->crc_table_free ? 2 : 0), reinterpret_cast<u32*>(m + 12), nullptr, nullptr, s), "crc32c");
+                                          1, (masked ? 1 : 0) | c->crc_bits(), reinterpret_cast<u32*>(m + 12), nullptr, nullptr, s), "crc32c");
     ok = ok && c->check(hipMemcpyAsync(&h, m, sizeof(h), hipMemcpyDeviceToHost, s), "D2H meta");
     ok = ok && c->check(hipStreamSynchronize(s), "sync");
     if (!ok) return SNP_ERR_DEVICE;

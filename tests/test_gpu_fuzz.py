@@ -343,17 +343,18 @@ def test_context_options_pin_layouts_without_changing_results():
 
 
 def test_crc32c_table_free_kernel_equals_the_table_kernel_and_the_oracle():
-    """SNP_OPT_CRC_TABLE_FREE (the kernel BASELINE.json's north star names: no table, the GF(2) shift map bit by bit) against the default
-    LDS-table kernel and the oracle (Crc32CAlgorithm.cs:41-158): ragged lengths 0 .. 70 000, masked and unmasked, and through the
+    """SNP_OPT_CRC_TABLE_FREE = 1 (the kernel BASELINE.json's north star names: no table, the GF(2) shift map bit by bit), 0 (the default: three
+    LDS tables of 11 + 11 + 10 bits, four byte ranges per wavefront -- so the ragged list also ends inside a wavefront's group of four) and 2 (round 3's
+    four 8-bit tables) against the oracle (Crc32CAlgorithm.cs:41-158): ragged lengths 0 .. 70 000, masked and unmasked, and through the
     framing format (snp_frame_encode computes every chunk's CRC with the selected kernel, snp_frame_decode verifies with it)."""
     N = S._native
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
     rng = np.random.default_rng(11)
-    lens = [0, 1, 2, 3, 4, 5, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 65535, 65536, 70000] + [int(x) for x in rng.integers(0, 70000, 200)]
+    lens = [0, 1, 2, 3, 4, 5, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 65535, 65536, 70000] + [int(x) for x in rng.integers(0, 70000, 201)]   # 218 ranges: not a multiple of 16
     blocks = [rng.integers(0, 256, n, dtype=np.uint8) for n in lens]
     data, off, ln = batch_of(blocks)
     want = {m: np.array([O.crc32c(b.tobytes(), masked=m) for b in blocks], dtype=np.uint32) for m in (False, True)}
-    for table_free in (1, 0, 1):
+    for table_free in (1, 0, 2, 1):
         cd.ctx.set_option(N.OPT_CRC_TABLE_FREE, table_free)
         assert cd.ctx.get_option(N.OPT_CRC_TABLE_FREE) == table_free
         for m in (False, True):
