@@ -137,7 +137,7 @@ snp_status snp_ctx_get_option(const snp_ctx* ctx, int option, int64_t* out_value
  * snp_compress_batch / snp_frame_encode* call (see SNP_OPT_TABLE_PROBE_TRIES: for >= 16 384 fragments that is a placement search of 0.3-6 s
  * over transient candidate memory).  A service calls it once at start-up, before its own buffers crowd the device: the first request then
  * pays nothing, and the search sees all of device memory -- and takes its time: it goes on looking for a third kind of memory (worth 4 % of
- * the compressor's rate) as far as SNP_OPT_TABLE_PROBE_TRIES / the byte cap / half of free memory allow, up to a few seconds.  Batches above 262 144 fragments run in slices, so that is the most it reserves.
+ * the compressor's rate) as far as the byte cap and three quarters of free memory allow (with SNP_OPT_TABLE_PROBE_TRIES set: that many workspaces' worth and half of free memory), up to ~8 seconds.  Batches above 262 144 fragments run in slices, so that is the most it reserves.
  * Later, larger batches still grow the workspace on demand.  SNP_OK, or SNP_ERR_DEVICE (snp_ctx_last_error says why). */
 snp_status snp_ctx_reserve_compress(snp_ctx* ctx, uint32_t nfragments);
 const char* snp_status_string(int status);

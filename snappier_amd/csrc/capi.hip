@@ -384,12 +384,16 @@ struct snp_ctx {
         const size_t piece_bytes = static_cast<size_t>(piece_frags) * 65536u;
         ps.n = (cap_frags + piece_frags - 1) / piece_frags;
         ps.piece_gib = piece_bytes / 1073741824.0;
-        ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(tries);
+        // snp_ctx_reserve_compress (thorough) with the default option: as many candidates as memory allows.  The kinds lie in runs of ~100 pieces in
+        // allocation order; processes were seen whose third kind began at candidate 176 and at 208, and one where 216 (half of free memory) did not
+        // reach it (bench 94 instead of 99.5 GB/s, profiles/r04ag_search_reach.txt) -- so the thorough search may hold three quarters of what is free.
+        const bool reach = thorough && !table_tries_set;
+        ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(reach && tries < 24 ? 24 : tries);   // (24 workspaces' worth: 384 pieces, more than three quarters of 288 GB hold at 163 840 fragments)
         ps.dbg = getenv("SNAPPIER_HIP_DEBUG") != nullptr;
         if (thorough) ps.patience = 64;                                       // snp_ctx_reserve_compress: the caller has time -- look for a third kind as far as max_cand allows
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {                // the candidates coexist: stay within half of what is free
-            size_t room = free_b / 2;                                        // ... and within the caller's byte cap (SNP_OPT_TABLE_PROBE_MAX_BYTES)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {                // the candidates coexist: stay within half (thorough: three quarters) of what is free
+            size_t room = reach ? free_b / 4 * 3 : free_b / 2;               // ... and within the caller's byte cap (SNP_OPT_TABLE_PROBE_MAX_BYTES)
             if (table_probe_max_bytes && table_probe_max_bytes < room) room = static_cast<size_t>(table_probe_max_bytes);
             if (room / piece_bytes < ps.max_cand) ps.max_cand = room / piece_bytes;
         }

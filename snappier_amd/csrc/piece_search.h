@@ -26,7 +26,7 @@ typedef uint32_t u32;
 //     pair's time falls between the two levels; a candidate that no reference explains becomes the next reference (up to four);
 //   * the 16 pieces are picked greedily so that the largest per-kind sum stays smallest; candidates keep coming until the largest kind's
 //     share of the set is <= 0.40-0.47 with three references (three kinds about evenly; <= 0.56, two kinds, from round `patience` on) or `max_cand`
-//     (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, half of free memory, the byte cap) is reached; a short hill climb on the COMPOSED
+//     (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, half of free memory, the byte cap; snp_ctx_reserve_compress with default options: 24 workspaces' worth, three quarters) is reached; a short hill climb on the COMPOSED
 //     probe polishes the result.
 // Cost: typically 0.5-1.2 s and three to six workspaces' worth of candidate memory (up to a few seconds and `max_cand` pieces when one kind is all
 // there is for a long while), once, at the first large compress call of a context or in snp_ctx_reserve_compress; the losers are freed
