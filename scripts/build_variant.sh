@@ -1,24 +1,35 @@
 #!/bin/bash
-# Builds snappier_amd/variants/libsnappier_hip_<name>.so with extra -D flags applied to ONE source (default decompress.hip); the other
-# sources are compiled once into a cache of objects.    scripts/build_variant.sh <name> [-DFOO=1 ...]      SRC=compress_lanes.hip to vary another file
+# Builds snappier_amd/variants/libsnappier_hip_<name>.so: the product sources with extra -D flags applied to ONE of them (default
+# decode_chains.hip); the other sources are compiled once into a cache of objects.
+#     scripts/build_variant.sh <name> [-DFOO=1 ...]        SRC=compress_lanes.hip to vary another file
+#     LAB=1 scripts/build_variant.sh lab                   the LAB library: lab/decompress_r04.hip in place of decompress.hip (every decoder front
+#                                                          end that was measured and lost), and -DSNAPPIER_HIP_DEBUG_ENV on every source (the
+#                                                          SNAPPIER_HIP_* knobs act: the product library reads no environment)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
-SRC=${SRC:-decompress.hip}
-OBJ=${OBJ_CACHE:-/tmp/snp_obj}
+SRC=${SRC:-decode_chains.hip}
+LAB=${LAB:-0}
+OBJ=${OBJ_CACHE:-/tmp/snp_obj}$([ "$LAB" = 1 ] && echo _lab)
 mkdir -p $OBJ snappier_amd/variants
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fconstexpr-steps=100000000 -Wno-sometimes-uninitialized -Wno-unused-function"
-for f in decompress decompress_small tag_index compress_lanes compress_win crc32c framing frame_scan capi; do
+DEC=decompress
+if [ "$LAB" = 1 ]; then FLAGS="$FLAGS -DSNAPPIER_HIP_DEBUG_ENV"; DEC=lab/decompress_r04; fi
+[ "$SRC" = decompress.hip ] && [ "$LAB" = 1 ] && SRC=lab/decompress_r04.hip
+FILES="decode_chains $DEC decompress_small tag_index compress_lanes compress_win crc32c framing frame_scan capi"
+newest_header=$(ls -t snappier_amd/csrc/*.h include/*.h | head -1)
+for f in $FILES; do
+  o=$OBJ/$(basename $f).o
   if [ "$f.hip" != "$SRC" ]; then
-    if [ ! -f $OBJ/$f.o ] || [ snappier_amd/csrc/$f.hip -nt $OBJ/$f.o ] || [ snappier_amd/csrc/snp_device.h -nt $OBJ/$f.o ] || [ include/snappier_hip.h -nt $OBJ/$f.o ]; then
-      /opt/rocm/bin/hipcc $FLAGS -c snappier_amd/csrc/$f.hip -o $OBJ/$f.o
+    if [ ! -f $o ] || [ snappier_amd/csrc/$f.hip -nt $o ] || [ $newest_header -nt $o ]; then
+      /opt/rocm/bin/hipcc $FLAGS -c snappier_amd/csrc/$f.hip -o $o
     fi
   fi
 done
 /opt/rocm/bin/hipcc $FLAGS "$@" -c snappier_amd/csrc/$SRC -o $OBJ/variant_$name.o
 objs=""
-for f in decompress decompress_small tag_index compress_lanes compress_win crc32c framing frame_scan capi; do
-  if [ "$f.hip" == "$SRC" ]; then objs="$objs $OBJ/variant_$name.o"; else objs="$objs $OBJ/$f.o"; fi
+for f in $FILES; do
+  if [ "$f.hip" == "$SRC" ]; then objs="$objs $OBJ/variant_$name.o"; else objs="$objs $OBJ/$(basename $f).o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-rpath,/opt/rocm/lib $objs -o snappier_amd/variants/libsnappier_hip_$name.so
 echo snappier_amd/variants/libsnappier_hip_$name.so

@@ -14,7 +14,7 @@ import re
 import torch  # noqa: F401  (must precede CDLL -- see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SNAPPIER_HIP_LIB") or os.path.join(HERE, "libsnappier_hip.so")   # override: kernel-variant A/B runs
+LIB_PATH = os.environ.get("SNAPPIER_HIP_LIB") or os.path.join(HERE, "libsnappier_hip.so")   # override: kernel-variant A/B runs (a LAB=1 build, if knobs are to act)
 HEADER_PATH = os.path.join(HERE, "..", "include", "snappier_hip.h")
 
 (OK, ERR_OUTPUT_TOO_SMALL, ERR_BAD_OFFSET, ERR_TOO_LONG, ERR_INCOMPLETE, ERR_BAD_LENGTH, ERR_CRC_MISMATCH,
@@ -36,12 +36,46 @@ def declared_symbols() -> list[str]:
 
 
 _lib = None
+_lab = None
+LAB_PATH = os.path.join(HERE, "variants", "libsnappier_hip_lab.so")
+# what selects the LAB library (see lib()): every SNAPPIER_HIP_* knob except the library override itself
+_NOT_KNOBS = ("SNAPPIER_HIP_LIB",)
+
+
+def debug_knobs_set() -> bool:
+    return any(k.startswith("SNAPPIER_HIP_") and k not in _NOT_KNOBS for k in os.environ)
+
+
+def lab_path() -> str:
+    """snappier_amd/variants/libsnappier_hip_lab.so, built on demand (LAB=1 scripts/build_variant.sh lab: the product sources with
+    -DSNAPPIER_HIP_DEBUG_ENV plus the decoder front ends of csrc/lab/)."""
+    import subprocess
+    script = os.path.join(HERE, "..", "scripts", "build_variant.sh")
+    srcs = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(HERE, "csrc", "lab", f) for f in os.listdir(os.path.join(HERE, "csrc", "lab"))]
+    srcs.append(os.path.join(HERE, "..", "include", "snappier_hip.h"))
+    if not os.path.exists(LAB_PATH) or any(os.path.getmtime(f) > os.path.getmtime(LAB_PATH) for f in srcs):
+        r = subprocess.run(["bash", script, "lab"], env=dict(os.environ, LAB="1"), capture_output=True, text=True)
+        if r.returncode != 0:
+            raise ImportError("building the lab library failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+    return LAB_PATH
 
 
 def lib() -> C.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
+    """The product library -- or, while any SNAPPIER_HIP_* knob is set in the environment (tests and A/B scripts that vary a kernel
+    layout), the LAB library, which is the only one that reads them.  A Context remembers the library it was created from."""
+    global _lib, _lab
+    if not os.environ.get("SNAPPIER_HIP_LIB") and debug_knobs_set():
+        if _lab is None:
+            _lab = _load(lab_path())
+        return _lab
+    if _lib is None:
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def _load(path: str) -> C.CDLL:
+    LIB_PATH = path
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python snappier_amd/build.py` "
                           "(there is no CPU fallback for the codec)")
@@ -91,7 +125,6 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = L
     return L
 
 

@@ -51,7 +51,7 @@ class BlockCodec:
             out = torch.empty(nb * self.comp_stride, dtype=torch.uint8, device=self.device)
         out_len = torch.empty(nb, dtype=torch.int32, device=self.device)
         status = torch.empty(nb, dtype=torch.int32, device=self.device)
-        st = N.lib().snp_compress_batch(self.ctx.handle, _p(data), _p(in_off), _p(in_len), nb, _p(out), _p(out_off),
+        st = self.ctx.lib.snp_compress_batch(self.ctx.handle, _p(data), _p(in_off), _p(in_len), nb, _p(out), _p(out_off),
                                         _p(out_len), _p(status))
         raise_for_status(st, self.ctx.handle)
         return out, out_off, out_len, status
@@ -63,7 +63,7 @@ class BlockCodec:
         nb = in_len.numel()
         out_len = torch.empty(nb, dtype=torch.int32, device=self.device)
         status = torch.empty(nb, dtype=torch.int32, device=self.device)
-        st = N.lib().snp_decompress_batch(self.ctx.handle, _p(comp), _p(in_off), _p(in_len), nb, _p(out), _p(out_off),
+        st = self.ctx.lib.snp_decompress_batch(self.ctx.handle, _p(comp), _p(in_off), _p(in_len), nb, _p(out), _p(out_off),
                                           _p(out_cap), _p(out_len), _p(status))
         raise_for_status(st, self.ctx.handle)
         return out_len, status
@@ -77,7 +77,7 @@ class BlockCodec:
         dst_off = torch.cumsum(lens, 0) - lens
         total = int(lens.sum().item()) if nb else 0
         out = torch.empty(total, dtype=torch.uint8, device=self.device)
-        st = N.lib().snp_concat_batch(self.ctx.handle, _p(data), _p(in_off), _p(in_len), nb, _p(out), _p(dst_off))
+        st = self.ctx.lib.snp_concat_batch(self.ctx.handle, _p(data), _p(in_off), _p(in_len), nb, _p(out), _p(dst_off))
         raise_for_status(st, self.ctx.handle)
         return out, dst_off
 
@@ -85,7 +85,7 @@ class BlockCodec:
         self._bind()
         nb = in_len.numel()
         crc = torch.empty(nb, dtype=torch.int32, device=self.device)
-        st = N.lib().snp_crc32c_batch(self.ctx.handle, _p(data), _p(in_off), _p(in_len), nb, int(masked), _p(crc))
+        st = self.ctx.lib.snp_crc32c_batch(self.ctx.handle, _p(data), _p(in_off), _p(in_len), nb, int(masked), _p(crc))
         raise_for_status(st, self.ctx.handle)
         return crc
 
@@ -104,7 +104,7 @@ class BlockCodec:
         if out.numel() < cap or work.numel() < need:
             raise ValueError("frame_encode: out/work buffers too small")
         written = torch.zeros(1, dtype=torch.int64, device=self.device)
-        st = N.lib().snp_frame_encode_device(self.ctx.handle, _p(raw), n, _p(out), cap, _p(written), _p(work))
+        st = self.ctx.lib.snp_frame_encode_device(self.ctx.handle, _p(raw), n, _p(out), cap, _p(written), _p(work))
         raise_for_status(st, self.ctx.handle)
         return out, written
 
@@ -113,7 +113,7 @@ class BlockCodec:
         nc = body_len.numel()
         out_len = torch.empty(nc, dtype=torch.int32, device=self.device)
         status = torch.empty(nc, dtype=torch.int32, device=self.device)
-        st = N.lib().snp_frame_decode_chunks_device(self.ctx.handle, _p(framed), _p(chunk_type), _p(body_off),
+        st = self.ctx.lib.snp_frame_decode_chunks_device(self.ctx.handle, _p(framed), _p(chunk_type), _p(body_off),
                                                     _p(body_len), _p(chunk_crc), nc, _p(out), _p(out_off), _p(out_cap),
                                                     _p(out_len), _p(status))
         raise_for_status(st, self.ctx.handle)
@@ -129,6 +129,6 @@ class BlockCodec:
         if work.numel() < need:
             raise ValueError("frame_decode: work buffer too small")
         result = torch.zeros(2, dtype=torch.int64, device=self.device)
-        st = N.lib().snp_frame_decode_device(self.ctx.handle, _p(framed), nbytes, _p(out), out.numel(), max_chunks, _p(work), _p(result))
+        st = self.ctx.lib.snp_frame_decode_device(self.ctx.handle, _p(framed), nbytes, _p(out), out.numel(), max_chunks, _p(work), _p(result))
         raise_for_status(st, self.ctx.handle)
         return result

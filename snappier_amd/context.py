@@ -17,7 +17,8 @@ class Context:
         """stream: a hipStream_t handle as an int (torch.cuda.current_stream().cuda_stream; 0 = the default stream),
         or None for a private non-blocking stream owned by the context."""
         self._h = C.c_void_p()
-        st = N.lib().snp_ctx_create(device, hash_variant, None, C.byref(self._h))
+        self.lib = N.lib()          # (the product library, or the lab one while a SNAPPIER_HIP_* knob is set: every call on this context goes to it)
+        st = self.lib.snp_ctx_create(device, hash_variant, None, C.byref(self._h))
         if st != N.OK:
             self._h = C.c_void_p()
             raise InvalidOperationException(
@@ -28,7 +29,7 @@ class Context:
             self.set_stream(stream)
 
     def set_stream(self, stream: int):
-        st = N.lib().snp_ctx_set_stream(self._h, C.c_void_p(stream))
+        st = self.lib.snp_ctx_set_stream(self._h, C.c_void_p(stream))
         if st != N.OK:
             raise InvalidOperationException(N.status_string(st))
 
@@ -38,36 +39,36 @@ class Context:
 
     def counter(self, which: int) -> int:
         """snp_ctx_counter: 0 = large blocks decoded per fragment, 1 = large blocks that fell back to one wavefront."""
-        return int(N.lib().snp_ctx_counter(self._h, which))
+        return int(self.lib.snp_ctx_counter(self._h, which))
 
     def set_option(self, option: int, value: int):
         """snp_ctx_set_option (N.OPT_*): kernels and memory behaviour only, never results."""
-        st = N.lib().snp_ctx_set_option(self._h, option, value)
+        st = self.lib.snp_ctx_set_option(self._h, option, value)
         if st != N.OK:
             raise ValueError(f"snp_ctx_set_option({option}, {value}): {N.status_string(st)}")
 
     def reserve_compress(self, nfragments: int):
         """snp_ctx_reserve_compress: build the lane compressor's hash-table workspace for batches of up to `nfragments` fragments now
         (a service's start-up, before its buffers crowd the device) instead of on the first large compress call."""
-        st = N.lib().snp_ctx_reserve_compress(self._h, int(nfragments))
+        st = self.lib.snp_ctx_reserve_compress(self._h, int(nfragments))
         if st != N.OK:
-            raise InvalidOperationException(f"snp_ctx_reserve_compress({nfragments}): {N.status_string(st)}: {N.lib().snp_ctx_last_error(self._h).decode()}")
+            raise InvalidOperationException(f"snp_ctx_reserve_compress({nfragments}): {N.status_string(st)}: {self.lib.snp_ctx_last_error(self._h).decode()}")
 
     def get_option(self, option: int) -> int:
         v = C.c_int64(0)
-        st = N.lib().snp_ctx_get_option(self._h, option, C.byref(v))
+        st = self.lib.snp_ctx_get_option(self._h, option, C.byref(v))
         if st != N.OK:
             raise ValueError(f"snp_ctx_get_option({option}): {N.status_string(st)}")
         return int(v.value)
 
     def synchronize(self):
-        st = N.lib().snp_ctx_synchronize(self._h)
+        st = self.lib.snp_ctx_synchronize(self._h)
         if st != N.OK:
-            raise InvalidOperationException(N.lib().snp_ctx_last_error(self._h).decode())
+            raise InvalidOperationException(self.lib.snp_ctx_last_error(self._h).decode())
 
     def close(self):
         if self._h:
-            N.lib().snp_ctx_destroy(self._h)
+            self.lib.snp_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -85,6 +86,7 @@ def default_context(hash_variant: int | None = None) -> Context:
     cache = getattr(_tls, "ctx", None)
     if cache is None:
         cache = _tls.ctx = {}
+    key = (key, N.debug_knobs_set())       # (a context belongs to the library it was created from)
     if key not in cache:
-        cache[key] = Context(0, key)
+        cache[key] = Context(0, key[0])
     return cache[key]

@@ -389,7 +389,7 @@ struct snp_ctx {
         // reach it (bench 94 instead of 99.5 GB/s, profiles/r04ag_search_reach.txt) -- so the thorough search may hold three quarters of what is free.
         const bool reach = thorough && !table_tries_set;
         ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(reach && tries < 24 ? 24 : tries);   // (24 workspaces' worth: 384 pieces, more than three quarters of 288 GB hold at 163 840 fragments)
-        ps.dbg = getenv("SNAPPIER_HIP_DEBUG") != nullptr;
+        ps.dbg = SNP_GETENV("SNAPPIER_HIP_DEBUG") != nullptr;
         if (thorough) ps.patience = 64;                                       // snp_ctx_reserve_compress: the caller has time -- look for a third kind as far as max_cand allows
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {                // the candidates coexist: stay within half (thorough: three quarters) of what is free
@@ -527,46 +527,47 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     // disables the token-parallel front end of the decompressor (bit 1 of the kernel mode)
     // FENCED (drain vmcnt before a wave reads output bytes it stored itself) is the default: measured 0.9 % slower than relying
     // on in-order vector memory (17.22 vs 17.38 ms per 10 GiB, profiles/r02c_fenced_ab.jsonl); SNAPPIER_HIP_FENCED=0 turns it off
-    const char* f = getenv("SNAPPIER_HIP_FENCED");
+    const char* f = SNP_GETENV("SNAPPIER_HIP_FENCED");
     c->fenced = (f && f[0] == '0') ? 0 : 1;
-    const char* m = getenv("SNAPPIER_HIP_DECODE");
+    const char* m = SNP_GETENV("SNAPPIER_HIP_DECODE");
     if (m && strcmp(m, "serial") == 0) c->fenced |= 2;
     if (m && strcmp(m, "batched") == 0) c->fenced |= 4;                 // token-parallel batches without the execution queue
     if (m && strcmp(m, "ring") == 0) c->fenced |= 8 | 32;              // sub-chain parse + output-granular execution through an LDS ring (FRONT = 4)
+    else if (m && strcmp(m, "chains_r04") == 0) c->fenced |= 8 | 64;   // the round-4 form of the default decoder (A/B)
     else if (!m || strcmp(m, "chains") == 0 || (strcmp(m, "queued") != 0 && strcmp(m, "serial") != 0 && strcmp(m, "batched") != 0))
         c->fenced |= 8;                                                 // default: sub-chain parse (decompress.hip, FRONT = 3); "queued" = 64-byte windows + queue
     c->decode_layout = (m && (strcmp(m, "serial") == 0 || strcmp(m, "batched") == 0)) ? 1 : 0;
     // SNAPPIER_HIP_DEC_LDS=<bytes>: dynamic LDS per decode wavefront, an occupancy throttle (160 KiB / bytes blocks per CU)
-    const char* dl = getenv("SNAPPIER_HIP_DEC_LDS");
+    const char* dl = SNP_GETENV("SNAPPIER_HIP_DEC_LDS");
     c->dec_lds = dl ? (atoi(dl) / 256) * 256 : kDefaultDecLds;
     // SNAPPIER_HIP_COMPRESS=win|lanes pins the compressor layout (default: by batch size)
-    const char* cm = getenv("SNAPPIER_HIP_COMPRESS");
+    const char* cm = SNP_GETENV("SNAPPIER_HIP_COMPRESS");
     c->compress_mode = (cm && strcmp(cm, "lanes") == 0) ? 2 : (cm && strcmp(cm, "wing") == 0) ? 4 : (cm && strncmp(cm, "win", 3) == 0) ? 3 : 0;
-    const char* wg = getenv("SNAPPIER_HIP_WIN_GTAB_MIN");
+    const char* wg = SNP_GETENV("SNAPPIER_HIP_WIN_GTAB_MIN");
     if (wg) c->win_gtab_min = static_cast<u32>(strtoul(wg, nullptr, 10));
-    const char* wn = getenv("SNAPPIER_HIP_WIN_NP");
+    const char* wn = SNP_GETENV("SNAPPIER_HIP_WIN_NP");
     if (wn) c->win_np = atoi(wn) == 2 ? 2 : 1;
-    const char* fs = getenv("SNAPPIER_HIP_FRAME_SCAN");
+    const char* fs = SNP_GETENV("SNAPPIER_HIP_FRAME_SCAN");
     c->frame_scan = (fs && strcmp(fs, "serial") == 0) ? 1 : 0;
-    const char* sm = getenv("SNAPPIER_HIP_SMALL_MAX");
+    const char* sm = SNP_GETENV("SNAPPIER_HIP_SMALL_MAX");
     if (sm) c->small_max = static_cast<u32>(strtoul(sm, nullptr, 10));
-    const char* sl = getenv("SNAPPIER_HIP_SMALL");
+    const char* sl = SNP_GETENV("SNAPPIER_HIP_SMALL");
     c->small_lanes = sl && strcmp(sl, "lanes") == 0;
     c->small_team_log = (sl && strcmp(sl, "team4") == 0) ? 2 : (sl && strcmp(sl, "team8") == 0) ? 3 : (sl && strcmp(sl, "team16") == 0) ? 4 : 0;
-    const char* rg = getenv("SNAPPIER_HIP_REDO");
+    const char* rg = SNP_GETENV("SNAPPIER_HIP_REDO");
     c->redo_grid = rg && strcmp(rg, "grid") == 0;
     c->redo_list = rg && strcmp(rg, "list") == 0;
-    const char* sn = getenv("SNAPPIER_HIP_SMALL_MIN");
+    const char* sn = SNP_GETENV("SNAPPIER_HIP_SMALL_MIN");
     if (sn) c->small_min_blocks = static_cast<u32>(strtoul(sn, nullptr, 10));
-    const char* sf = getenv("SNAPPIER_HIP_SLICE");
+    const char* sf = SNP_GETENV("SNAPPIER_HIP_SLICE");
     if (sf && atoi(sf) >= 4096) c->slice_fragments = static_cast<u32>(atoi(sf));
-    const char* wm = getenv("SNAPPIER_HIP_WIN_MAX");
+    const char* wm = SNP_GETENV("SNAPPIER_HIP_WIN_MAX");
     if (wm) c->win_max = static_cast<u32>(strtoul(wm, nullptr, 10));
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
     // fragments decoded in parallel (tag_index.hip); 0 = always one wavefront per block
-    const char* tt = getenv("SNAPPIER_HIP_TABLE_TRIES");
+    const char* tt = SNP_GETENV("SNAPPIER_HIP_TABLE_TRIES");
     if (tt) { c->table_tries = atoi(tt) < 1 ? 1 : atoi(tt) > 16 ? 16 : atoi(tt); c->table_tries_set = true; }
-    const char* pm = getenv("SNAPPIER_HIP_PARALLEL_MIN");
+    const char* pm = SNP_GETENV("SNAPPIER_HIP_PARALLEL_MIN");
     if (pm) c->par_min = static_cast<u32>(strtoul(pm, nullptr, 10));
     *out_ctx = c;
     return SNP_OK;
@@ -1106,7 +1107,7 @@ snp_status decompress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uin
             bool all_ok = true;
             for (u32 f = 0; f < nf; ++f) all_ok = all_ok && st[f] == SNP_OK;
             ++c->counters[all_ok ? 0 : 1];
-            if (!all_ok && getenv("SNAPPIER_HIP_DEBUG")) {
+            if (!all_ok && SNP_GETENV("SNAPPIER_HIP_DEBUG")) {
                 std::vector<u64> ent(nent), fo(nf);
                 std::vector<u32> sk(nf), il(nf);
                 (void)hipMemcpy(ent.data(), c->work.p, nent * 8ull, hipMemcpyDeviceToHost);

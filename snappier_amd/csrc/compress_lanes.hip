@@ -746,7 +746,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     hipLaunchKernelGGL(k_max_len, dim3(mgrid), dim3(256), 0, stream, in_len, nblocks, max_len);
     // Fragments per wavefront: 64 when there are enough fragments to fill the chip that way; fewer (partially filled
     // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
-    const char* env = getenv("SNAPPIER_HIP_LANES_PER_WAVE");
+    const char* env = SNP_GETENV("SNAPPIER_HIP_LANES_PER_WAVE");
     const bool two_probes = (lanes_per_wave & 256) != 0;               // the context's hint: small fragments (capi.hip)
     const u32 small_hint = ((static_cast<u32>(lanes_per_wave) >> 9) & 63u) << 4;   // ... and, when they are small enough for it, the LDS slot size of the SMALL launch
     lanes_per_wave &= 255;
@@ -761,13 +761,13 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // the tables are no longer the only thing the memory system is busy with, same-process A/B: html 99.45 -> 97.29 ms, mixed 146.0 -> 144.6,
     // low entropy 35.75 -> 35.58; mid-size batches lose 1-2 % and do not get it).  SNAPPIER_HIP_EXACT_LITERALS=1 = none (exact-length stores only);
     // SNAPPIER_HIP_CL_OPTS=<mask> picks a subset -- read per launch, so one process can A/B on the same workspace.
-    const char* ex = getenv("SNAPPIER_HIP_EXACT_LITERALS");
-    const char* oe = getenv("SNAPPIER_HIP_CL_OPTS");
+    const char* ex = SNP_GETENV("SNAPPIER_HIP_EXACT_LITERALS");
+    const char* oe = SNP_GETENV("SNAPPIER_HIP_CL_OPTS");
     // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
-    const char* ab = getenv("SNAPPIER_HIP_CL_ABLATE");              // (acts in -DSNP_CL_ABLATE_RT=1 builds only: timing-only ablations, bits 8.. of the option word)
+    const char* ab = SNP_GETENV("SNAPPIER_HIP_CL_ABLATE");              // (acts in -DSNP_CL_ABLATE_RT=1 builds only: timing-only ablations, bits 8.. of the option word)
     const int lit_blind = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0))) | ((SNP_CL_ABLATE_RT && ab) ? (atoi(ab) & 8191) << 8 : 0);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
-    const char* se = getenv("SNAPPIER_HIP_CL_SLOTS");
+    const char* se = SNP_GETENV("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
     // one probe is 1.5 % faster at 163 840)
     // (... and for batches of SMALL fragments at any size -- bit 8 of lanes_per_wave is the context's hint for them: they are latency-bound, not
@@ -778,11 +778,11 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     // 512 B 47.8 -> 60.7-62.6, 768 B 49.6 -> 51.3; 64 B and 1 KiB lose).  The launch with the input in LDS goes first; each of the two launches
     // checks max_len on the device and returns if the batch is the other one's.  SNAPPIER_HIP_CL_SMALL=0 never launches it, =<bytes> forces
     // its slot size; SNAPPIER_HIP_CL_SMALL_PER = its lanes per wavefront.
-    const char* sm = getenv("SNAPPIER_HIP_CL_SMALL");
+    const char* sm = SNP_GETENV("SNAPPIER_HIP_CL_SMALL");
     u32 small_max = sm ? (static_cast<u32>(atoi(sm)) + 15u) & ~15u : small_hint;
     if (small_max > 2048) small_max = 0;
     if (small_max) {
-        const char* sp = getenv("SNAPPIER_HIP_CL_SMALL_PER");
+        const char* sp = SNP_GETENV("SNAPPIER_HIP_CL_SMALL_PER");
         u32 sper = sp ? static_cast<u32>(atoi(sp)) : 32u;
         if (sper != 64 && sper != 32 && sper != 16) sper = 32;
         const u32 sgrid = (nblocks + sper - 1) / sper;

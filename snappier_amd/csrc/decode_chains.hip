@@ -1,0 +1,490 @@
+// decode_chains.hip -- k_decode_chains: the default block decoder, one Snappy block per wavefront (gfx950).
+//
+// Replaces the tag loop of SnappyDecompressor.DecompressAllTags + Append / AppendFromSelf
+// (Snappier/Internal/SnappyDecompressor.cs:184-347,568-611; copy semantics CopyHelpers.cs:222-230) for whole blocks.
+//
+// The kernel is bound by instruction issue, so everything here is shaped by instruction count, not by bytes moved.
+//
+//   PARSE, one SUPER-WINDOW of 64 x 32 = 2 KiB of compressed input at a time.  Where do the tags start?  Every lane walks a chain of tags
+//   through its own 32-byte region, starting blindly at the region's first byte.  A chain that starts inside a tag reads garbage, but a
+//   garbage chain and the true chain that land on the same byte are the same chain from there on, and they meet within a few tags:
+//     S   the input is staged into LDS not as bytes but as a table of tag ADVANCES -- tab[p] = bytes from a tag that starts at p to the
+//         next tag (2 / 3 / 5 for copies, 2..61 for literals, 62..65 = a literal with length bytes) -- computed four bytes per instruction
+//         on the dwords as they arrive from global memory; the walks below are then one LDS byte read per tag and no decode;
+//     A   lane k walks region k from its first byte, marks what it visits (bit 7 of the table entry; its own 32-bit mask V_k);
+//     A'  it walks on past the region's end until it lands on a marked entry (the chains have merged: m_k, next lane nx_k), recording
+//         these overrun positions in a per-lane bitmap (kCap = 128 bytes far at most);
+//     R   lane 0's chain is the true one (the super-window starts at a tag): the lanes reachable from lane 0 along nx are the lanes
+//         whose chains are true from their entry on (pointer doubling over the lanes);
+//     T   true tag starts = each such lane's V_k from its entry on, plus its overrun positions: a 2048-bit map whose popcount prefix
+//         numbers the tags; the positions are written out as a u16 list (over the table).
+//
+//   EXECUTE, 64 tags at a time, one per lane: tag bytes (one 8-byte load per lane, requested a batch ahead) -> decode -> DPP prefix sum
+//   of the output lengths -> the batch's bytes are assembled in a 2 KiB LDS stage and leave as one coalesced write:
+//     pass 1  literals and copies whose source lies below the batch: 16-byte pieces from global memory into the stage;
+//     pass 2  copies whose source lies inside the batch and is not the output of a tag that is still pending (a bitmap of pending
+//             output bytes decides), lane-parallel, stage to stage;
+//     finish  what is left (dependency chains inside the batch, pattern copies), in order, whole wave per tag, a byte per lane.
+//   A batch ends before the first tag it cannot take (malformed, a literal > 64 bytes, the last 16 output bytes): a long literal is
+//   copied by the whole wave and parsing goes on; anything else falls to serial_tail(), which owns the reference's error semantics.
+#include "decode_common.h"
+
+// Phase markers for scripts/isa_budget.py (comments in the assembly: no instructions, no barriers beyond `volatile`).
+#define SNP_MARK(name) asm volatile("; MARK " #name)
+
+namespace {
+
+constexpr u32 kR = 32;                  // input bytes per lane region
+constexpr u32 kW = SNP_WAVE * kR;       // the super-window
+constexpr u32 kCap = 128;               // a chain may overrun its region by this much before the wave takes over (multiple of 32)
+constexpr u32 kStage = 2048;            // output bytes of a batch (64 tags of <= 64 bytes could span 4096: a batch is cut at this)
+
+// Advance of the tag that starts with byte c, for the four bytes of a dword at once (Constants.cs:42-76: tag byte, 0..4 trailer bytes,
+// the body of a literal): copy-1 / 2 / 4 -> 2 / 3 / 5; literal of h + 1 <= 60 bytes -> h + 2; literal with 1..4 length bytes -> 62..65.
+__device__ __forceinline__ u32 adv4(u32 x)
+{
+    const u32 k1 = 0x01010101u;
+    const u32 t = x & 0x03030303u;
+    const u32 t1 = t >> 1;
+    const u32 hp = ((x >> 2) & 0x3f3f3f3fu) + 0x02020202u;             // literals: h + 2 (<= 65: no carry between the bytes)
+    const u32 ca = t + k1 + (t1 & t & k1);                              // copies: 1 -> 2, 2 -> 3, 3 -> 5
+    const u32 nz = ((t | t1) & k1) * 255u;                              // 0xff in the bytes whose tag is a copy
+    return (ca & nz) | (hp & ~nz);
+}
+
+__device__ __forceinline__ u32x4 adv16(u32x4 v) { return u32x4{adv4(v.x), adv4(v.y), adv4(v.z), adv4(v.w)}; }
+
+// The advance of a literal with length bytes (table value a = 62..65) at input position `at` (read from global memory: rare).
+__device__ __forceinline__ u32 long_literal_advance(const u8* at, u32 a)
+{
+    const u32 ex = a - 61u;                                             // 1..4 length bytes
+    const u32 b1234 = ld32u(at + 1);
+    const u32 tr = ex >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * ex);
+    return 2u + ex + min(tr, 0x3fffffffu);                              // saturates so that positions stay below 2^31
+}
+
+// Stores into the stage are exact; LOADS are not: a lane reads whole 16-byte pieces, so one memory round trip serves every size class and
+// the 8/4/2/1-byte stores of a short tag are cut out of the registers.  The caller guarantees that reading up to 15 bytes past a source is
+// safe.  Every vector-memory instruction costs the texture path ~40 cycles whatever its lane count: none is issued needlessly.
+// The first 16-byte piece p0 of a tag of len bytes into the stage at d: whole when len >= 16, else as exact 8 / 4 / 2 / 1-byte pieces, each
+// cut from the front of what is left of the 16 bytes.
+__device__ __forceinline__ void store_first_piece(u8* d, u32x4 p0, u32 len)
+{
+    if (len >= 16u) {
+        st128u(d, p0);
+    } else {
+        const bool c8 = (len & 8u) != 0, c4 = (len & 4u) != 0, c2 = (len & 2u) != 0;
+        const u32 a0 = c8 ? p0.z : p0.x;
+        const u32 a1 = c8 ? p0.w : p0.y;
+        const u32 b0 = c4 ? a1 : a0;
+        const u32 c0 = c2 ? b0 >> 16 : b0;
+        if (c8) st64u(d, p0.x, p0.y);
+        if (c4) st32u(d + (len & 8u), a0);
+        if (c2) st16u(d + (len & 12u), b0);
+        if (len & 1u) d[len & 14u] = static_cast<u8>(c0);
+    }
+}
+
+// One lane copies len (1..64) bytes from s (global memory or the stage) into the stage at d: first and last 16 bytes (one round trip for
+// every tag of <= 32 bytes), then the two middle pieces of a longer one.  `any_mid`: some lane of the wave has len > 32 (wave-uniform: the
+// middle pieces are skipped by a scalar branch otherwise).
+__device__ __forceinline__ void copy_into_stage(u8* d, const u8* s, u32 len, bool any_mid)
+{
+    const u32x4 p0 = ld128u(s);
+    u32x4 p1, p2, p3;                                                   // read only where they were loaded
+    if (len > 16u) p1 = ld128u(s + len - 16);
+    const bool mid = len > 32u;
+    if (any_mid) {
+        if (mid) {
+            p2 = ld128u(s + 16);
+            p3 = ld128u(s + min(32u, len - 16u));
+            asm volatile("" ::"v"(p2), "v"(p3));                        // (both in flight together: the compiler must not sink the second)
+        }
+    }
+    store_first_piece(d, p0, len);
+    if (len > 16u) st128u(d + len - 16, p1);
+    if (any_mid) {
+        if (mid) {
+            st128u(d + 16, p2);
+            if (len > 48u) st128u(d + 32, p3);
+        }
+    }
+}
+
+// FRAG: one 64 KiB fragment of a larger block (decode_common.h): tags that end at or before the fragment's start (`dead`) are parsed, never
+// produced; a tag that straddles the start, or a copy that reaches back before it, is not taken (serial_tail answers kIrregular).
+template <bool FENCED, bool FRAG>
+__device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
+{
+    __shared__ __attribute__((aligned(16))) u8 c_tab[kW + 64];          // the advance table (+ 64 sentinels); afterwards the tag positions (u16 each, <= kW / 2 of them)
+    __shared__ __attribute__((aligned(16))) u8 c_stage[kStage + 64];    // a batch's output; while a super-window is built: flags, entries, overrun bitmaps
+    __shared__ u64 c_busy[65];                                          // batches: pending output bytes; while a super-window is built: the tag-start map
+    u32* const c_T = reinterpret_cast<u32*>(c_busy);
+    u16* const c_pos = reinterpret_cast<u16*>(c_tab);
+    const u8* const src = B.src;
+    u8* const dst = B.dst;
+    const u32 n = B.n, expected = B.expected;
+    const u32 skip = FRAG ? B.skip : 0u;
+    u32 op = B.op;
+    const u32 r0 = kR * lane;
+    u32 wbase = B.ip, ntok = 0, emitted = 0, consumed = 0;
+    u32 q_pf = 0;                                                       // tag bytes of the batch that starts at list index pf_at,
+    u32 pf_at = ~0u;                                                    // requested while the batch before it executes
+    for (;;) {
+        if (emitted == ntok) {
+            // ---- the next super-window ----
+SNP_MARK(S_stage_table);
+            wbase += consumed;
+            consumed = 0;
+            if (wbase + 72 > n || op >= expected) break;
+            const u32 avail = n - wbase;
+            const u32 L = min(kW, avail) - 8u;                          // tags may start below L: their 8 bytes lie inside the input
+            const u8* const wsrc = src + wbase;
+            {
+                // S: 2 x 16 bytes per lane; a piece that would cross the end of the input is pulled back inside it (avail >= 72; the entries
+                // it rewrites are the same entries), pieces beyond it are not needed
+                const u32 oa = lane * 16u, ob = oa + 1024u;
+                const u32 la = min(oa, avail - 16u), lb = min(ob, avail - 16u);
+                const u32x4 va = ld128u(wsrc + la), vb = ld128u(wsrc + lb);
+                st128u(c_tab + la, adv16(va));
+                st128u(c_tab + lb, adv16(vb));
+                lanes_sync_lds();
+                c_tab[L + lane] = 64;                                   // sentinels: a chain that gets here has left the window (entries < 62 + 64 bytes on)
+            }
+            lanes_sync_lds();
+SNP_MARK(A_walk);
+            // A: the chain from the first byte of the lane's region.  A literal with length bytes (a >= 62) ends the walk whatever its
+            // real length -- p + 62 is past the region -- and is sorted out below, off the loop.
+            u32 p = r0, V = 0, a = 0;
+            const u32 lim = min(r0 + kR, L);
+            while (p < lim) {
+                a = c_tab[p];
+                c_tab[p] = static_cast<u8>(a | 0x80u);
+                V |= 1u << (p & 31u);
+                p += a;
+            }
+SNP_MARK(Aprime_walk);
+            c_T[lane] = 0;
+            u32* const c_O = reinterpret_cast<u32*>(c_stage + 512) + lane * (kCap / 32);   // overrun positions, a bit each, from obase
+#pragma unroll
+            for (u32 w = 0; w < kCap / 32; ++w) c_O[w] = 0;
+            lanes_sync_lds();
+            // A': on past the region until the chain lands on a marked entry, on a literal with length bytes, kCap bytes away, or on
+            // the sentinels past the window.  A literal with length bytes is where a chain STOPS in both walks (its length bytes are
+            // not in the table): if it lies on the true path, the wave follows it below (`unresolved`).  One loop exit, at the top.
+            const bool stopA = (p > r0) & (a >= 62u);                   // the region walk ended on one: the chain stands there, marked
+            p = stopA ? p - a : min(p, L + 63u);                        // (an idle region past the input: onto a sentinel -- what lies beyond them is stale)
+            const u32 obase = p & ~(kR - 1u);
+            u32* const c_Ob = c_O - (obase >> 5);                       // word of position q: c_Ob[q >> 5]
+            a = c_tab[p];
+            u32 x = a | ((p - obase) & ~(kCap - 1u));                   // >= 62: stop (kCap is a power of two)
+            while (x < 62u) {
+                atomicOr(&c_Ob[p >> 5], 1u << (p & 31u));
+                p += a;
+                a = c_tab[p];
+                x = a | ((p - obase) & ~(kCap - 1u));
+            }
+            // where the chain merged (nx = that lane), left the super-window (64), or stopped unresolved (65)
+            const u32 nx = stopA ? 65u : (a & 0x80u) ? p >> 5 : (p >= L ? 64u : 65u);
+SNP_MARK(R_reach);
+            const u32 m = p;                                            // where the chain merged, gave up or left
+            // R: the lanes on the true chain = the lanes reachable from lane 0 along nx, by pointer doubling (flags through LDS: a
+            // scatter needs its senders masked); each of them tells its successor where it enters.
+            u64 active;
+            u32 entry = 0;
+            {
+                u8* const c_reach = c_stage;                            // (the stage is idle while a super-window is built)
+                u32* const c_entry = reinterpret_cast<u32*>(c_stage + SNP_WAVE);
+                u32 hop = nx;
+                bool reached = lane == 0;
+                c_reach[lane] = reached ? 1 : 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    lanes_sync_lds();
+                    if (reached && hop < 64u) c_reach[hop] = 1;
+                    lanes_sync_lds();
+                    reached = c_reach[lane] != 0;
+                    const u32 h2 = bperm(hop, hop);
+                    hop = hop < 64u ? h2 : hop;
+                }
+                if (reached && nx < 64u) c_entry[nx] = m;
+                lanes_sync_lds();
+                if (lane) entry = c_entry[lane];
+                lanes_sync_lds();
+                active = ballot64(reached);
+                const u64 ends = ballot64(reached && nx == 64u);        // the lane whose chain leaves the super-window, if the chain gets there
+                consumed = ends ? read_lane(m, static_cast<u32>(__builtin_ctzll(ends))) : 0u;
+            }
+            if (ballot64(((active >> lane) & 1ull) && nx == 65u)) {
+                // a chain on the true path did not merge within kCap bytes (rare: ~2 per block on html): follow the path lane by lane on the
+                // scalar unit instead, walking such a chain on, whole wave, until it merges or leaves (tag bytes from global memory)
+                active = 0;
+                entry = 0;
+                for (u32 k = 0, e = 0;;) {
+                    active |= 1ull << k;
+                    entry = lane == k ? e : entry;
+                    u32 mk = read_lane(m, k), nk = read_lane(nx, k);
+                    if (nk == 65u) {
+                        nk = 64u;
+                        for (bool first = true; mk < L; first = false) {
+                            u32 a = bcast_first(static_cast<u32>(c_tab[mk]));
+                            if (!first && a >= 128u) { nk = mk >> 5; break; }   // (the entry it stands on may be its own mark)
+                            a &= 0x7fu;
+                            if (lane == 0) atomicOr(&c_T[mk >> 5], 1u << (mk & 31u));
+                            if (a >= 62u) a = bcast_first(long_literal_advance(wsrc + mk, a));
+                            mk += a;
+                        }
+                    }
+                    if (nk >= 64u) { consumed = mk; break; }
+                    e = mk;
+                    k = nk;
+                }
+            }
+SNP_MARK(T_list);
+            // T: the true tag starts
+            if ((active >> lane) & 1ull) {
+                const u32 own = V & ~((1u << (entry & 31u)) - 1u);
+                const u32 w0 = obase >> 5;
+                if (own) atomicOr(&c_T[lane], own);
+#pragma unroll
+                for (u32 w = 0; w < kCap / 32; ++w) {
+                    const u32 ow = c_O[w];
+                    if (ow && w0 + w < SNP_WAVE) atomicOr(&c_T[w0 + w], ow);
+                }
+            }
+            lanes_sync_lds();
+            const u32 Tw = c_T[lane];
+            const u32 cnt = static_cast<u32>(__builtin_popcount(Tw));
+            const u32 cincl = wave_inclusive_scan(cnt);
+            ntok = read_lane(cincl, 63);
+            lanes_sync_lds();                                           // (every read of the table is done: the list overwrites it)
+            u32 t = cincl - cnt, bits = Tw;
+            while (bits) {
+                c_pos[t++] = static_cast<u16>(r0 + static_cast<u32>(__builtin_ctz(bits)));
+                bits &= bits - 1u;
+            }
+            lanes_sync_lds();
+            emitted = 0;
+            pf_at = ~0u;
+            if (ntok == 0) {                                            // (cannot happen: position 0 is always a tag start; guards the loop)
+                consumed = 0;
+                break;
+            }
+        }
+SNP_MARK(B_top);
+        // ---- one batch: the next <= 64 tags of the list ----
+        const u32 t = emitted + lane;
+        const bool have = t < ntok;
+        const u32 pos = c_pos[have ? t : emitted];                      // (idle lanes re-read the batch's first position)
+        // The tag bytes were requested a batch ago (q_pf); only the first batch of a super-window loads them here, and that load's wait
+        // stays on ITS path: merged at a join, the compiler would drain vmcnt -- the previous batch's write-out -- in EVERY batch.
+        // (FOUR bytes per tag: a dword gather costs the texture path half of what the 8-byte one did, and only a copy-4 or a literal
+        //  with four length bytes -- which no 64 KiB-fragment compressor emits -- has a fifth byte: fetched below, when one shows up)
+        u32 q = q_pf;
+        if (pf_at != emitted) {
+            q = ld32u(src + wbase + pos);
+            asm volatile("" : "+v"(q));
+        }
+        const u32 c = q & 0xffu;
+        const u32 type = c & 3u;
+        const u32 hi6 = c >> 2;
+        u32 b1234 = q >> 8;
+        if (__builtin_expect(ballot64(have & ((type == 3u) | (c == 0xfcu))) != 0ull, 0)) {
+            if ((type == 3u) | (c == 0xfcu)) b1234 |= static_cast<u32>(src[wbase + pos + 4u]) << 24;
+        }
+        const bool is_lit = type == 0;
+        const bool long_lit = is_lit && hi6 >= 60;
+        const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
+        const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
+        const u32 len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);
+        const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
+        const u32 body = pos + 1u + extra;                              // a literal's bytes, from wbase
+        const u32 olen = have ? len : 0u;
+        const u32 incl = wave_inclusive_scan(olen);
+        const u32 drel = incl - olen;                                   // the tag's first output byte, from the batch's
+        const u32 room = n - wbase - 16u;                               // copy_into_stage over-reads 15 bytes
+        const bool lit_ok = ((len - 1u) < room) & (body <= room - len);
+        const bool dead = FRAG && op + incl <= skip;                    // ends at or before the fragment's start: parsed only
+        const bool live = !FRAG || op + drel >= skip;
+        const bool copy_ok = (off - 1u) < op + drel - skip;
+        const bool ok = have & (dead ? (!is_lit | lit_ok) : live & ((is_lit & lit_ok) | (!is_lit & copy_ok))) & (incl + 16u <= expected - op);
+        const bool big = is_lit & (len > 64u);
+        const u64 okm = ballot64(ok & !big & (incl <= kStage));
+        const u32 ne = okm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~okm));
+SNP_MARK(B_ne0);
+        if (ne == 0) {
+            const u32 f0 = read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), 0);
+            if (f0 != 3u) {                                             // not ours: the serial loop decides, from this tag on
+                wbase += read_lane(pos, 0);
+                consumed = 0;
+                break;
+            }
+            const u32 l0 = read_lane(len, 0);
+            if (!FRAG || read_lane(dead ? 1u : 0u, 0) == 0u) wave_copy(dst + op, src + wbase + read_lane(body, 0), l0, lane);
+            op += l0;
+            emitted += 1;
+            continue;
+        }
+SNP_MARK(B_pass1);
+        const bool act = lane < ne;
+        const u32 span = read_lane(incl, ne - 1);
+        const u32 srel = drel - off;                                    // source, from the batch's first byte (wraps when below it)
+        const bool ready = act & live & (is_lit | (off >= drel + len));   // copies: the source ends at or below the batch's first byte
+        if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pf_at = emitted + ne;                                           // the next batch's tag bytes travel with this batch's copies
+        if (pf_at < ntok) q_pf = ld32u(src + wbase + c_pos[pf_at + lane < ntok ? pf_at + lane : pf_at]);
+        u8* const my = c_stage + drel;
+        const u32 sofs_mine = is_lit ? wbase + body : op + srel;        // the source, from src (literals) or dst (copies)
+        const bool any_mid = ballot64(act & (len > 32u)) != 0ull;
+        if (ready) copy_into_stage(my, (is_lit ? src : dst) + sofs_mine, len, any_mid);
+SNP_MARK(B_finish);
+        u64 pend = ballot64(act & live & !ready);
+        if (pend) {
+            const bool plain = (off >= len) & (off <= drel);            // not a pattern copy, source entirely inside the batch
+            // The rest in order, whole wave per tag, a byte per lane.  One packed word per tag (v_readlane): destination, length, and
+            // either the source inside the stage or a flag for the slow form (pattern copy, source that starts below the batch).
+            const u32 pk = drel | (len << 11) | (plain ? srel << 18 : 0x80000000u);
+            while (pend) {
+                const u32 f = static_cast<u32>(__builtin_ctzll(pend));
+                pend ^= 1ull << f;
+                const u32 k = read_lane(pk, f);
+                if (__builtin_expect(static_cast<i32>(k) >= 0, 1)) {
+                    const u32 f_d = k & 0x7ffu, f_len = (k >> 11) & 0x7fu, f_s = k >> 18;
+                    if (lane < f_len) c_stage[f_d + lane] = c_stage[f_s + lane];
+                    lanes_sync_lds();
+                    continue;
+                }
+                // the slow form: a pattern copy (off < len: CopyHelpers.cs:222-230 copies byte by byte), or a source that starts below the batch
+                const u32 f_d = k & 0x7ffu, f_len = (k >> 11) & 0x7fu;
+                const u32 f_off = read_lane(off, f);
+                const u32 sidx = f_off < f_len ? lane_mod(lane, f_off) : lane;
+                const u32 spos = f_d + sidx - f_off;                    // from the batch's first byte; wraps when below it
+                u32 byte = 0;
+                if (lane < f_len) {
+                    if (static_cast<i32>(spos) < 0) byte = dst[op + spos];          // (two branches: one select would make this a flat load)
+                    else byte = c_stage[spos];
+                }
+                if (lane < f_len) c_stage[f_d + lane] = static_cast<u8>(byte);
+                lanes_sync_lds();
+            }
+        }
+SNP_MARK(B_writeout);
+        // the whole run, coalesced, in 16-byte units: the last one may carry up to 15 stale bytes past the run -- every batch ends at least
+        // 16 bytes short of the block's end (`ok`), and what follows (the next batch, the serial loop) stores over them in order
+        lanes_sync_lds();
+        u8* const g = dst + op;
+        if (FRAG && op < skip) {                                        // the batch the fragment starts in: nothing before its first byte is written
+            for (u32 i = skip - op + lane; i < span; i += SNP_WAVE) g[i] = c_stage[i];
+        } else {
+            for (u32 i = lane * 16; i < span; i += SNP_WAVE * 16)
+                *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(c_stage + i);
+        }
+        lanes_sync_lds();
+        op += span;
+        emitted += ne;
+    }
+SNP_MARK(Z_exit);
+    B.ip = wbase;                                                       // (every exit leaves consumed = 0)
+    B.op = op;
+    B.w.wv = 0x80000000u;                                               // the serial loop re-seats its window
+}
+
+template <bool FENCED, bool FRAG>
+__device__ __forceinline__ void decode_block_chains(SNP_D_PARAMS, const u32 b)
+{
+    const u32 lane = lane_id();
+    DecBlk B;
+    if (!block_begin<FRAG>(SNP_D_ARGS, b, lane, B)) return;
+    if (B.st == SNP_OK) chains_front<FENCED, FRAG>(B, lane);
+    serial_tail<FENCED, FRAG>(B, b, lane, out_len, status);
+}
+
+// 64 VGPRs: eight wavefronts per SIMD.
+#ifdef SNP_DC_VGPRS
+#define SNP_DC_ATTR __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_vgpr(SNP_DC_VGPRS)))
+#else
+#define SNP_DC_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+template <bool FENCED>
+__global__ __launch_bounds__(SNP_WAVE) SNP_DC_ATTR void k_decode_chains(SNP_D_PARAMS)
+{
+    decode_block_chains<FENCED, false>(SNP_D_ARGS, blockIdx.x);
+}
+
+// One wavefront per 64 KiB output fragment of one large block (tag_index.hip found where each begins).
+template <bool FENCED>
+__global__ __launch_bounds__(SNP_WAVE) SNP_DC_ATTR void k_decode_chains_frag(SNP_D_PARAMS)
+{
+    decode_block_chains<FENCED, true>(SNP_D_ARGS, blockIdx.x);
+}
+
+// The same over a LIST of blocks: the blocks the small-block pre-pass (decompress_small.hip) did not finish, which it appended to
+// `list` in 64 sub-lists (ctl[s] = length of sub-list s).  Persistent: the grid is one chip-full of wavefronts and each takes list
+// entries by ticket (ctl[64]) until the list is empty -- when the pre-pass finished everything (millions of small blocks) this launch
+// costs microseconds instead of one empty workgroup per block, and when it finished nothing the wavefronts decode ~20 blocks each.
+template <bool FENCED>
+__global__ __launch_bounds__(SNP_WAVE) SNP_DC_ATTR void k_decode_chains_list(
+    SNP_D_PARAMS, const u32* __restrict__ list, u32* __restrict__ ctl, u32 sub_cap)
+{
+    const u32 lane = lane_id();
+    const u32 mine = __hip_atomic_load(&ctl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 incl = wave_inclusive_scan(mine);
+    const u32 count = read_lane(incl, 63);
+    // tickets are taken several at a time (one counter for 2 M small blocks was the whole run time); a wavefront's first tickets are
+    // its by position, only the later ones come from the counter
+    const u32 grab = min(max(count / (gridDim.x * 8u), 1u), 64u);
+    for (u32 first = blockIdx.x * grab; first < count;) {
+        const u32 last = min(first + grab, count);
+        for (u32 i = first; i < last; ++i) {
+            const u32 sub = static_cast<u32>(__builtin_popcountll(ballot64(incl <= i)));   // the sub-list ticket i falls into
+            const u32 before = read_lane(incl - mine, sub);
+            decode_block_chains<FENCED, false>(SNP_D_ARGS, list[static_cast<u64>(sub) * sub_cap + (i - before)]);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the next block reuses the LDS arrays)
+        }
+        u32 next = 0;
+        if (lane == 0) next = atomicAdd(&ctl[64], grab);
+        first = gridDim.x * grab + bcast_first(next);
+    }
+}
+
+}  // namespace
+
+// lds_bytes: dynamic LDS requested per wavefront purely to cap how many blocks a CU decodes at once (0 = no cap).
+extern "C" hipError_t snp_launch_decode_chains(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out, const u64* out_off,
+                                               const u32* out_cap, u32* out_len, i32* status, const u8* chunk_type, int fenced, int redo_only,
+                                               unsigned lds_bytes, hipStream_t stream, const u32* frag_skip)
+{
+    if (nblocks == 0) return hipSuccess;
+    if (frag_skip) {                                    // fragments of one large block (tag_index.hip)
+        if (fenced)
+            hipLaunchKernelGGL((k_decode_chains_frag<true>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks, out, out_off,
+                               out_cap, out_len, status, nullptr, frag_skip, 0);
+        else
+            hipLaunchKernelGGL((k_decode_chains_frag<false>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks, out, out_off,
+                               out_cap, out_len, status, nullptr, frag_skip, 0);
+        return hipGetLastError();
+    }
+    const u32* const no_skip = nullptr;
+    if (fenced)
+        hipLaunchKernelGGL((k_decode_chains<true>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks, out, out_off,
+                           out_cap, out_len, status, chunk_type, no_skip, redo_only);
+    else
+        hipLaunchKernelGGL((k_decode_chains<false>), dim3(nblocks), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks, out, out_off,
+                           out_cap, out_len, status, chunk_type, no_skip, redo_only);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t snp_launch_decode_chains_list(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out, const u64* out_off,
+                                                    const u32* out_cap, u32* out_len, i32* status, const u8* chunk_type, int fenced,
+                                                    unsigned lds_bytes, hipStream_t stream, const u32* list, u32* ctl, u32 waves, u32 sub_cap)
+{
+    if (nblocks == 0) return hipSuccess;
+    const u32* const no_skip = nullptr;
+    if (fenced)
+        hipLaunchKernelGGL((k_decode_chains_list<true>), dim3(waves), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks, out, out_off,
+                           out_cap, out_len, status, chunk_type, no_skip, 0, list, ctl, sub_cap);
+    else
+        hipLaunchKernelGGL((k_decode_chains_list<false>), dim3(waves), dim3(SNP_WAVE), lds_bytes, stream, in, in_off, in_len, nblocks, out, out_off,
+                           out_cap, out_len, status, chunk_type, no_skip, 0, list, ctl, sub_cap);
+    return hipGetLastError();
+}

@@ -406,7 +406,7 @@ extern "C" hipError_t snp_launch_decompress_small(const u8* in, const u64* in_of
                            out_cap, out_len, status, chunk_type, lim, list, ctl, sub_cap);
         return hipGetLastError();
     }
-    const char* be = getenv("SNAPPIER_HIP_TEAM_BUDGET");                // LDS bytes per wavefront (experiments; default below)
+    const char* be = SNP_GETENV("SNAPPIER_HIP_TEAM_BUDGET");                // LDS bytes per wavefront (experiments; default below)
     const u32 budget = be && atoi(be) >= 1024 && atoi(be) <= 65536 ? static_cast<u32>(atoi(be)) / 16 * 16 : (team_budget ? team_budget : kTeamBudget);
     const bool dense = budget <= 5120;                                  // 32 wavefronts per CU fit by LDS: let the registers allow them too
 #define SNP_LAUNCH_TEAMS(T)                                                                                             \

@@ -40,7 +40,7 @@ class Snappy:
         ctx = ctx or default_context()
         src, dst = _view(input), output
         w = C.c_size_t(0)
-        st = N.lib().snp_try_compress(ctx.handle, _ptr(src), src.size, _ptr(dst), dst.size, C.byref(w))
+        st = ctx.lib.snp_try_compress(ctx.handle, _ptr(src), src.size, _ptr(dst), dst.size, C.byref(w))
         if st == N.ERR_OUTPUT_TOO_SMALL:
             return False, 0
         raise_for_status(st, ctx.handle)
@@ -75,7 +75,7 @@ class Snappy:
         ctx = ctx or default_context()
         src, dst = _view(input), output
         w = C.c_size_t(0)
-        st = N.lib().snp_try_decompress(ctx.handle, _ptr(src), src.size, _ptr(dst), dst.size, C.byref(w))
+        st = ctx.lib.snp_try_decompress(ctx.handle, _ptr(src), src.size, _ptr(dst), dst.size, C.byref(w))
         if st == N.ERR_OUTPUT_TOO_SMALL:
             return False, 0
         raise_for_status(st, ctx.handle)
@@ -109,7 +109,7 @@ def crc32c(data, masked: bool = False, ctx: Context | None = None) -> int:
     ctx = ctx or default_context()
     src = _view(data)
     v = C.c_uint32(0)
-    st = N.lib().snp_crc32c(ctx.handle, _ptr(src), src.size, int(masked), C.byref(v))
+    st = ctx.lib.snp_crc32c(ctx.handle, _ptr(src), src.size, int(masked), C.byref(v))
     raise_for_status(st, ctx.handle)
     return v.value
 
@@ -121,7 +121,7 @@ def frame_encode(data, ctx: Context | None = None) -> bytes:
     cap = N.lib().snp_frame_max_encoded_length(src.size)
     out = np.empty(cap, dtype=np.uint8)
     w = C.c_size_t(0)
-    st = N.lib().snp_frame_encode(ctx.handle, _ptr(src), src.size, _ptr(out), out.size, C.byref(w))
+    st = ctx.lib.snp_frame_encode(ctx.handle, _ptr(src), src.size, _ptr(out), out.size, C.byref(w))
     raise_for_status(st, ctx.handle)
     return out[: w.value].tobytes()
 
@@ -135,6 +135,6 @@ def frame_decode(data, ctx: Context | None = None) -> bytes:
     # header-walk errors are re-reported by snp_frame_decode in stream order, after the chunks before them
     out = np.empty(total.value, dtype=np.uint8)
     w = C.c_size_t(0)
-    st = N.lib().snp_frame_decode(ctx.handle, _ptr(src), src.size, _ptr(out), out.size, C.byref(w))
+    st = ctx.lib.snp_frame_decode(ctx.handle, _ptr(src), src.size, _ptr(out), out.size, C.byref(w))
     raise_for_status(st, ctx.handle)
     return out[: w.value].tobytes()

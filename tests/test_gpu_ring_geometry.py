@@ -22,7 +22,7 @@ def test_ring_decoder_with_a_one_kib_ring_round_trips(tmp_path):
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc on this host: the variant cannot be built")
-    env = dict(os.environ, OBJ_CACHE=str(tmp_path / "obj"))
+    env = dict(os.environ, OBJ_CACHE=str(tmp_path / "obj"), LAB="1", SRC="decompress.hip")   # the ring is a lab front end (csrc/lab/decompress_r04.hip)
     r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "build_variant.sh"), "test_ring1k", "-DSNP_D_RING=1024", "-DSNP_D_RING_SPAN=512"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
