@@ -262,7 +262,7 @@ def pmc_rows(directory: str, counter: str) -> dict:
     for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                m = re.search(r"(k_(?:compress|decompress)[a-z_0-9]*)", r["Kernel_Name"])
+                m = re.search(r"(k_(?:compress|decompress|decode)[a-z_0-9]*)", r["Kernel_Name"])
                 if m and r["Counter_Name"] == counter and int(r["Grid_Size"]) >= 64 * 64:      # (not the few-wavefront helpers)
                     per.setdefault(m.group(1), []).append(float(r["Counter_Value"]) * 1024.0)
     return per
@@ -302,7 +302,7 @@ def live_traffic(nb: int, hash_name: str, config: int):
 def traffic_profile():
     """Per-block FETCH_SIZE + WRITE_SIZE of the committed PMC passes (rocprofv3 --pmc, one counter per pass, same workload).
     Replayed, never measured in the bench process: the object says which profile, from which commit, over how many launches."""
-    for cand in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02p_hbm_traffic.json", "r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
+    for cand in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02p_hbm_traffic.json", "r02_hbm_traffic.json", "r01k_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 doc = json.load(f)
@@ -328,6 +328,8 @@ def main():
     ap.add_argument("--config5-lines", action="store_true",
                     help="after the measured workload, also run configs[4] (mixed corpus, block-sharded) and report config5_lines; "
                          "on by default when --gpus > 1")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip `other_configs` (N = 1 only: BASELINE configs[2], configs[3] and the configs[4] share, 3 steps each, and the CRC kernel; ~15 s)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -365,7 +367,9 @@ def main():
     nb = args.blocks
     free, _tot = torch.cuda.mem_get_info()
     need = nb * (2 * BLOCK + 76512) + (3 << 30)
+    reduced_from = None
     if free < need:
+        reduced_from = nb
         nb = int((free - (3 << 30)) // (2 * BLOCK + 76512)) // 1024 * 1024
         print(f"[bench] only {free >> 30} GiB free: reduced to {nb} blocks per GPU", file=sys.stderr)
 
@@ -547,6 +551,76 @@ def main():
                  "rank0_compression_ratio": round(c5 / u_bytes, 4),
                  "verified": "decode(encode(x)) == x for every block of every rank's shard" if True else None}
 
+    # ---- other_configs (N = 1): BASELINE configs[2] (low entropy), configs[3] (framing) and the configs[4] share (mixed corpus) on the same buffers,
+    # 3 steps each, verified; and the CRC kernel alone.  Never part of `value`.
+    other = None
+    if world == 1 and not args.no_other_configs and not extra:
+        other = []
+        def block_config(name, data):
+            tc, tdd = [], []
+            def one():
+                e0, e1, e2 = ev(), ev(), ev()
+                e0.record()
+                _o, _oo, ol, stt = cd.compress(data, in_off, in_len, out=comp, out_off=comp_off)
+                e1.record()
+                dl, ds = cd.decompress(comp, comp_off, ol, back, in_off, in_len)
+                e2.record()
+                tc.append((e0, e1)); tdd.append((e1, e2))
+                return ol, stt, dl, ds
+            one()
+            tc.clear(); tdd.clear()
+            for _ in range(3):
+                ol, stt, dl, ds = one()
+            torch.cuda.synchronize()
+            ok = int((stt != 0).sum()) == 0 and int((ds != 0).sum()) == 0 and bool((dl == BLOCK).all()) and torch.equal(back, data)
+            cb = float(ol.to(torch.int64).sum().item())
+            mc = float(np.mean([a.elapsed_time(b) for a, b in tc])); md = float(np.mean([a.elapsed_time(b) for a, b in tdd]))
+            other.append({"workload": name, "blocks": nb, "steps": 3, "compression_ratio": round(cb / u_bytes, 4), "verified": ok,
+                          "compress_GBps": round(u_bytes / mc / 1e6, 2), "decompress_GBps": round(u_bytes / md / 1e6, 2),
+                          "compress_ms": round(mc, 3), "decompress_ms": round(md, 3),
+                          "roofline_compress_frac": round((u_bytes + cb) / mc / 1e6 / HBM_PEAK_GBPS, 5),
+                          "roofline_decompress_frac": round((u_bytes + cb) / md / 1e6 / HBM_PEAK_GBPS, 5)})
+        del raw
+        raw = SD.low_entropy_blocks(0, nb, dev)
+        block_config(f"configs[2]: {nb} low-entropy (~90 % match) 64 KiB blocks", raw)
+        del raw
+        raw = make_blocks(5)
+        block_config(f"configs[4], one GPU's share: {nb} mixed-corpus 64 KiB blocks (block b = corpus file b mod 11)", raw)
+        del raw
+        raw = make_blocks(2)
+        # the CRC kernel alone (framing's masked CRC-32C of every 64 KiB chunk)
+        tcr = []
+        cd.crc32c(raw, in_off, in_len, masked=True)
+        for _ in range(3):
+            e0, e1 = ev(), ev()
+            e0.record(); crc = cd.crc32c(raw, in_off, in_len, masked=True); e1.record()
+            tcr.append((e0, e1))
+        torch.cuda.synchronize()
+        ms_crc = float(np.mean([a.elapsed_time(b) for a, b in tcr]))
+        other.append({"workload": f"masked CRC-32C of {nb} 64 KiB chunks (k_crc32c)", "steps": 3, "ms": round(ms_crc, 3), "GBps": round(u_bytes / ms_crc / 1e6, 1),
+                      "roofline_frac": round(u_bytes / ms_crc / 1e6 / HBM_PEAK_GBPS, 4)})
+        # configs[3]: the framing format end to end on the device (compress + CRC + raw-vs-compressed + headers; then header walk + decode + CRC verify)
+        from snappier_amd import _native as N2
+        f_out = torch.empty(N2.lib().snp_frame_max_encoded_length(raw.numel()), dtype=torch.uint8, device=dev)
+        f_work = torch.empty(N2.lib().snp_frame_encode_workspace(raw.numel()), dtype=torch.uint8, device=dev)
+        def t3(fn):
+            fn()
+            ts = []
+            for _ in range(3):
+                e0, e1 = ev(), ev()
+                e0.record(); r = fn(); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return float(np.mean(ts)), r
+        ms_e, (framed, written) = t3(lambda: cd.frame_encode(raw, f_out, f_work))
+        w = int(written.item())
+        back.zero_()
+        d_work = torch.empty(N2.lib().snp_frame_decode_workspace(nb + 16), dtype=torch.uint8, device=dev)
+        ms_w, res = t3(lambda: cd.frame_decode(framed, w, back, nb + 16, d_work))
+        ok4 = res.cpu().tolist() == [int(u_bytes), 0] and torch.equal(back, raw)
+        other.append({"workload": f"configs[3]: SnappyStream framing over {nb} html-like 64 KiB chunks, device resident (encode; header walk + decode + CRC verify)",
+                      "steps": 3, "framed_bytes": w, "verified_crc_and_bytes": ok4, "frame_encode_GBps": round(u_bytes / ms_e / 1e6, 2),
+                      "frame_decode_verify_GBps": round(u_bytes / ms_w / 1e6, 2), "frame_encode_ms": round(ms_e, 3), "frame_decode_ms": round(ms_w, 3)})
+        del f_out, f_work, d_work
     if rank == 0:
         total_u = u_bytes * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -576,7 +650,7 @@ def main():
                     "algorithmic_bytes_per_launch": int(alg),
                     "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}
         r_c = roof(ms_c, "k_compress_lanes" if lanes else "k_compress_win")
-        r_d = roof(ms_d, "k_decompress_chains" if "k_decompress_chains" in pmc else "k_decompress")
+        r_d = roof(ms_d, "k_decode_chains")
         if lanes:
             r_c["table_workspace_probe"] = {"chosen_ms": S.lib().snp_ctx_counter(cd.ctx.handle, 2) / 1e3,
                                             "candidates": S.lib().snp_ctx_counter(cd.ctx.handle, 3)}
@@ -601,11 +675,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[1]: 10 GiB of 64 KiB html-like blocks per GPU, " if args.config == 2 else
-                                    "configs[4]: 10 GiB of mixed-corpus 64 KiB blocks per GPU (80 GiB at 8 GPUs), ") +
+            "config": {"workload": (f"configs[1]: {nb} html-like 64 KiB blocks ({nb * BLOCK / 2**30:.2f} GiB) per GPU, " if args.config == 2 else
+                                    f"configs[4]: {nb} mixed-corpus 64 KiB blocks ({nb * BLOCK / 2**30:.2f} GiB) per GPU, ") +
+                                   (f"REDUCED from {reduced_from} blocks (device memory short), " if reduced_from else "") +
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
-                       "layout": "decompress: one block per wavefront (sub-chain tag parse over 2 KiB super-windows, 64 tags per execution batch staged in LDS); compress: one fragment per lane, hash tables in an HBM workspace of 16 pieces spread over the kinds of device memory, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
+                       "layout": "decompress: one block per wavefront (k_decode_chains: sub-chain tag parse over 2 KiB super-windows through an LDS table of tag advances, 64 tags per execution batch staged in LDS); compress: one fragment per lane, hash tables in an HBM workspace of 16 pieces spread over the kinds of device memory, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
                        "workspace": "hash-table workspace built by snp_ctx_reserve_compress before the buffers are allocated (a service's start-up; untimed, like the setup pass)" if not os.environ.get("BENCH_NO_RESERVE") else "hash-table workspace built by the untimed setup pass",
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
@@ -620,6 +695,8 @@ def main():
         }
         if extra:
             line["config5_lines"] = extra
+        if other:
+            line["other_configs"] = other
         if cpu_sample is not None:
             line["cpu_baseline"] = cpu_baseline(cpu_sample, variant)
         print(json.dumps(line), flush=True)

@@ -34,18 +34,27 @@ public sealed class GpuContext : SafeHandle
         ctx = t_current;
         if (ctx is { IsInvalid: false, IsClosed: false }) return true;
         if (s_unavailable) { ctx = null; return false; }
-        ctx = Create(DefaultDevice, DefaultHash);
+        ctx = Create(DefaultDevice, DefaultHash, default, out bool permanent);
         t_current = ctx;
-        if (ctx is null) s_unavailable = true;
+        if (ctx is null && permanent) s_unavailable = true;     // (a transient failure -- out of memory on one thread, a busy device -- is retried by the next call)
         return ctx is not null;
     }
 
-    public static GpuContext? Create(int device, SnpHash hash, IntPtr hipStream = default)
+    public static GpuContext? Create(int device, SnpHash hash, IntPtr hipStream = default) => Create(device, hash, hipStream, out _);
+
+    /// <summary>permanent: the library or its entry point is missing, or snp_ctx_create answered Device / BadArg (no such device, no HIP runtime):
+    /// nothing a retry would change.  Any other failure is left to the next call.</summary>
+    private static GpuContext? Create(int device, SnpHash hash, IntPtr hipStream, out bool permanent)
     {
-        SnpStatus st;
-        try { st = NativeMethods.snp_ctx_create(device, (int)hash, hipStream, out IntPtr h); if (st == SnpStatus.Ok) { var c = new GpuContext(); c.SetHandle(h); return c; } }
-        catch (DllNotFoundException) { }
-        catch (EntryPointNotFoundException) { }
+        permanent = false;
+        try
+        {
+            SnpStatus st = NativeMethods.snp_ctx_create(device, (int)hash, hipStream, out IntPtr h);
+            if (st == SnpStatus.Ok) { var c = new GpuContext(); c.SetHandle(h); return c; }
+            permanent = st == SnpStatus.Device || st == SnpStatus.BadArg;
+        }
+        catch (DllNotFoundException) { permanent = true; }
+        catch (EntryPointNotFoundException) { permanent = true; }
         return null;
     }
 

@@ -43,12 +43,18 @@ public static unsafe class Snappy
         if (!GpuContext.IsAvailable) return true;
         byte[] probe = new byte[70000];
         for (int i = 0; i < probe.Length; ++i) probe[i] = (byte)((i * 31 + (i >> 7)) & 0x3f);
-        int saved = MinGpuCompressBytes;
-        MinGpuCompressBytes = 0;
-        byte[] gpu = CompressToArray(probe);
-        MinGpuCompressBytes = saved;
+        // the probe goes to the GPU directly: the routing thresholds are shared state and are not touched (a concurrent caller, or an exception
+        // here, must not find them at 0)
+        byte[] gpuBuf = new byte[GetMaxCompressedLength(probe.Length)];
+        int gpuLen;
+        fixed (byte* pin = probe)
+        fixed (byte* pout = gpuBuf)
+        {
+            ThrowIfFailed(NativeMethods.snp_try_compress(GpuContext.Current.Handle, pin, (nuint)probe.Length, pout, (nuint)gpuBuf.Length, out nuint w));
+            gpuLen = checked((int)w);
+        }
         byte[] managed = global::Snappier.Snappy.CompressToArray(probe);
-        bool same = gpu.AsSpan().SequenceEqual(managed);
+        bool same = gpuBuf.AsSpan(0, gpuLen).SequenceEqual(managed);
         if (!same) { MinGpuCompressBytes = 0; MinGpuDecompressBytes = 0; }
         return same;
     }

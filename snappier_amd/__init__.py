@@ -9,5 +9,6 @@ from .context import Context, default_context  # noqa: F401
 from .errors import InsufficientBufferException, InvalidDataException, InvalidOperationException  # noqa: F401
 from .snappy import Snappy, crc32c, frame_decode, frame_encode  # noqa: F401
 from .stream import CompressionMode, SnappyStream  # noqa: F401
+from .multidevice import MultiDeviceCodec  # noqa: F401
 
 lib()   # fail loudly at import time if the native library is missing or incomplete
