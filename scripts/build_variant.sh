@@ -10,12 +10,13 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 SRC=${SRC:-decode_chains.hip}
 LAB=${LAB:-0}
-OBJ=${OBJ_CACHE:-/tmp/snp_obj}$([ "$LAB" = 1 ] && echo _lab)
+OBJ=${OBJ_CACHE:-/tmp/snp_obj}
+if [ "$LAB" = 1 ]; then OBJ=${OBJ}_lab; fi
 mkdir -p $OBJ snappier_amd/variants
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fconstexpr-steps=100000000 -Wno-sometimes-uninitialized -Wno-unused-function"
 DEC=decompress
 if [ "$LAB" = 1 ]; then FLAGS="$FLAGS -DSNAPPIER_HIP_DEBUG_ENV"; DEC=lab/decompress_r04; fi
-[ "$SRC" = decompress.hip ] && [ "$LAB" = 1 ] && SRC=lab/decompress_r04.hip
+if [ "$SRC" = decompress.hip ] && [ "$LAB" = 1 ]; then SRC=lab/decompress_r04.hip; fi
 FILES="decode_chains $DEC decompress_small tag_index compress_lanes compress_win crc32c framing frame_scan capi"
 newest_header=$(ls -t snappier_amd/csrc/*.h include/*.h | head -1)
 for f in $FILES; do
