@@ -378,8 +378,12 @@ def main():
         html = f.read()
     cd = SB.BlockCodec(local_rank, variant)
     if not os.environ.get("BENCH_NO_RESERVE"):
-        # what a service does at start-up: the compressor's hash-table workspace is built before the buffers exist, so
-        # the placement search sees all of device memory.  Untimed either way: without it the setup pass below pays.
+        # what a service does at start-up: the device's hash-table workspace is built before the buffers exist, so the placement
+        # search sees all of device memory -- and the THOROUGH search is asked for explicitly (the library's default holds two
+        # workspaces' worth of candidates at most; what that default is worth is measured below as value_default_search).  Untimed either way.
+        from snappier_amd import _native as N0
+        cd.ctx.set_option(N0.OPT_TABLE_PROBE_TRIES, int(os.environ.get("BENCH_TABLE_TRIES", "24")))
+        cd.ctx.set_option(N0.OPT_TABLE_PROBE_MAX_BYTES, int(free // 4 * 3))        # (the third kind of device memory has been seen to begin beyond the first half)
         cd.ctx.reserve_compress(nb)
 
     def make_blocks(kind: int):
@@ -491,6 +495,44 @@ def main():
                  "decompress_ms": round(float(np.mean([a.elapsed_time(b) for a, b in p_dec])), 3),
                  "workspace": "one hipMalloc of 64 KiB per fragment (SNP_OPT_TABLE_PROBE_TRIES = 1: no placement search), second context, same buffers"}
         del cd2
+    # ---- what the library's DEFAULT options give: a fresh pool (every context of this process is gone), no option set, no reserve call -------
+    default_search = None
+    if lanes and world == 1 and not os.environ.get("BENCH_NO_DEFAULT_SEARCH"):
+        import gc
+        from snappier_amd import batch as SB2
+        comp_stride = cd.comp_stride
+        cd = None
+        gc.collect()                                            # the device's table pool dies with its last context
+        cd = SB2.BlockCodec(local_rank, variant)
+        assert cd.comp_stride == comp_stride
+        d_comp, d_dec = [], []
+        def default_step():
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            _o, _oo, ol, stt = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
+            e1.record()
+            dl, ds = cd.decompress(comp, comp_off, ol, back, in_off, in_len)
+            e2.record()
+            d_comp.append((e0, e1)); d_dec.append((e1, e2))
+            return ol, stt, dl, ds
+        t_s0 = time.perf_counter()
+        default_step()                                          # the first large compress call of the process's new pool: pays the bounded search
+        torch.cuda.synchronize()
+        first_call_s = time.perf_counter() - t_s0
+        d_comp.clear(); d_dec.clear()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            r = default_step()
+        torch.cuda.synchronize()
+        d_el = (time.perf_counter() - t0) / 3
+        if not verified(*r):
+            sys.exit("[bench] default-search round trip is NOT bit-exact")
+        default_search = {"value_GBps_this_gpu": round(u_bytes / d_el / 1e9, 3), "steps": 3,
+                          "compress_ms": round(float(np.mean([a.elapsed_time(b) for a, b in d_comp])), 3),
+                          "decompress_ms": round(float(np.mean([a.elapsed_time(b) for a, b in d_dec])), 3),
+                          "first_call_seconds": round(first_call_s, 3),
+                          "search": {"candidates": int(cd.ctx.counter(3)), "transient_bytes": int(cd.ctx.counter(5)), "seconds": round(cd.ctx.counter(4) / 1e6, 3)},
+                          "workspace": "library defaults: no option set, no snp_ctx_reserve_compress; the pool is built by the first compress call with this process's buffers already allocated"}
     # ---- per-rank decomposition (N >= 1): which rank was slow, and in which part; the directory gather alone ----
     t_gd = 0.0
     if distributed:
@@ -652,8 +694,7 @@ def main():
         r_c = roof(ms_c, "k_compress_lanes" if lanes else "k_compress_win")
         r_d = roof(ms_d, "k_decode_chains")
         if lanes:
-            r_c["table_workspace_probe"] = {"chosen_ms": S.lib().snp_ctx_counter(cd.ctx.handle, 2) / 1e3,
-                                            "candidates": S.lib().snp_ctx_counter(cd.ctx.handle, 3)}
+            r_c["table_workspace_probe"] = {"chosen_ms": search["chosen_set_probe_ms"], "candidates": search["candidates"]}
         if lanes and args.config == 2:
             # What bounds the lane compressor is not U + C but the random accesses of its hash tables: the reference
             # parse makes 9928 probes + 4228 post-copy inserts per fragment of this workload (counted on the CPU with the oracle), each
@@ -681,7 +722,7 @@ def main():
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
                        "layout": "decompress: one block per wavefront (k_decode_chains: sub-chain tag parse over 2 KiB super-windows through an LDS table of tag advances, 64 tags per execution batch staged in LDS); compress: one fragment per lane, hash tables in an HBM workspace of 16 pieces spread over the kinds of device memory, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
-                       "workspace": "hash-table workspace built by snp_ctx_reserve_compress before the buffers are allocated (a service's start-up; untimed, like the setup pass)" if not os.environ.get("BENCH_NO_RESERVE") else "hash-table workspace built by the untimed setup pass",
+                       "workspace": "the device's hash-table workspace built by snp_ctx_reserve_compress before the buffers are allocated, with the THOROUGH placement search asked for explicitly (SNP_OPT_TABLE_PROBE_TRIES = 24; a service's start-up: untimed, like the setup pass; its cost is workspace_search, what the default bounded search gives is value_default_search)" if not os.environ.get("BENCH_NO_RESERVE") else "hash-table workspace built by the untimed setup pass",
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,
@@ -691,6 +732,7 @@ def main():
             "verified": "decode(encode(x)) == x for every block, all status OK",
             "workspace_search": search if lanes else None,
             "value_plain_workspace": plain,
+            "value_default_search": default_search,
             "per_rank": per_rank,
         }
         if extra:

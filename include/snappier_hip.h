@@ -107,20 +107,24 @@ typedef enum snp_option {
      * 4 = the per-wavefront kernel with its table in a global-memory slot instead of LDS (measured +5 % only: never chosen by itself). */
     SNP_OPT_COMPRESS_LAYOUT = 4,
     SNP_OPT_COMPRESS_WINDOW_MAX_BATCH = 5,   /* default 16384 */
-    /* The lane compressor keeps 64 KiB of hash table per fragment of a launch in an HBM workspace the context owns (10.7 GB for
-     * 163 840 fragments; batches above 262 144 fragments run in slices).  How fast HBM serves its random traffic depends on where
-     * the driver placed the memory: device memory consists of regions of several kinds, and the traffic runs 20-25 % faster spread
-     * evenly over two or three kinds than confined to one.  So when a workspace of >= 1 GiB is first needed -- on the
-     * first large snp_compress_batch of a context, and again whenever a larger batch makes it grow -- the context builds it from up to
-     * 16 separately allocated pieces chosen by measurement: candidate pieces (1/16 of the workspace each) are allocated 16 at a time
-     * and probed in pairs (5 ms per probe) until a balanced set exists -- typically 48 candidates = three workspaces' worth for half a
-     * second -- or SNP_OPT_TABLE_PROBE_TRIES workspaces' worth of candidates (default 16, 1 = no search: one allocation) have been tried.
-     * MEMORY BEHAVIOUR: the candidates coexist until the search ends, within min(half of the device's free memory,
-     * SNP_OPT_TABLE_PROBE_MAX_BYTES) (default 0 = no further cap); a process that shares the GPU with other allocators should set
-     * the byte cap (or tries = 1) before its first large compress call.  The losers are freed before the call returns.
-     * WHERE the thorough search runs (round 4): in snp_ctx_reserve_compress.  The search a compress CALL triggers by itself is held to
-     * two workspaces' worth of candidates (one transient extra workspace, a few hundred ms) unless this option was set explicitly, in
-     * which case it is honoured as given -- a request must not take seconds or crowd a shared device behind the caller's back. */
+    /* The lane compressor keeps 64 KiB of hash table per fragment of a launch in an HBM workspace (10.7 GB for 163 840 fragments; batches
+     * above 262 144 fragments run in slices).  The workspace belongs to the DEVICE, not to the context: every context on a device borrows the
+     * same one for the duration of a launch sequence (a GPU-side event orders the borrowers; no host thread blocks), so eight caller
+     * threads cost one workspace, not eight (the reference pools one table per compressor: HashTable.cs:22-55).  It is built by the first
+     * large compress call on the device (or snp_ctx_reserve_compress), grows when a larger batch arrives, and is freed with the device's
+     * last context.
+     * PLACEMENT: how fast HBM serves the tables' random traffic depends on where the driver placed the memory -- device memory consists of
+     * regions, tens of GiB long, of three kinds, and the traffic runs 20-25 % faster spread evenly over two or three kinds than confined to
+     * one.  So a workspace of >= 1 GiB is built from up to 16 separately allocated pieces chosen by measurement:
+     * candidate pieces (1/16 of the workspace each) are allocated 16 at a time and probed in pairs (5 ms per probe) until a balanced set
+     * exists or the budget is spent; the losers are freed before the call returns.
+     * BUDGET (round 5): by DEFAULT the candidates never exceed TWO workspaces' worth (one transient extra workspace, a few hundred ms)
+     * nor half of the device's free memory -- a library must not take seconds or crowd a shared device on its own account.  Fresh device
+     * memory costs the driver ~27 ms per GiB to hand out, and the third kind may lie 150 GB of allocations away: a caller that wants the
+     * thorough search (worth ~5 % of the compressor's rate) asks for it -- SNP_OPT_TABLE_PROBE_TRIES = 3..24 workspaces' worth, within half of
+     * free memory or, when SNP_OPT_TABLE_PROBE_MAX_BYTES is set, within that many bytes (honoured up to 7/8 of what is free: the third kind has
+     * been seen to begin beyond the first half) -- and runs it at start-up through snp_ctx_reserve_compress.
+     * SNP_OPT_TABLE_PROBE_TRIES = 1: no search and no pool -- this context keeps a plain one-allocation workspace of its own. */
     SNP_OPT_TABLE_PROBE_TRIES = 6,
     SNP_OPT_TABLE_PROBE_MAX_BYTES = 7,
     SNP_OPT_PARALLEL_DECODE_MIN = 8,    /* snp_try_decompress: declared bytes from which ONE block is decoded a wavefront per 64 KiB fragment (0 = never; default 262144) */
@@ -133,12 +137,13 @@ typedef enum snp_option {
 } snp_option;
 snp_status snp_ctx_set_option(snp_ctx* ctx, int option, int64_t value);
 snp_status snp_ctx_get_option(const snp_ctx* ctx, int option, int64_t* out_value);
-/* Builds the lane compressor's hash-table workspace for batches of up to `nfragments` 64 KiB fragments NOW instead of on the first large
- * snp_compress_batch / snp_frame_encode* call (see SNP_OPT_TABLE_PROBE_TRIES: for >= 16 384 fragments that is a placement search of 0.3-6 s
- * over transient candidate memory).  A service calls it once at start-up, before its own buffers crowd the device: the first request then
- * pays nothing, and the search sees all of device memory -- and takes its time: it goes on looking for a third kind of memory (worth 4 % of
- * the compressor's rate) as far as the byte cap and three quarters of free memory allow (with SNP_OPT_TABLE_PROBE_TRIES set: that many workspaces' worth and half of free memory), up to ~8 seconds.  Batches above 262 144 fragments run in slices, so that is the most it reserves.
- * Later, larger batches still grow the workspace on demand.  SNP_OK, or SNP_ERR_DEVICE (snp_ctx_last_error says why). */
+/* Builds the device's hash-table workspace for batches of up to `nfragments` 64 KiB fragments NOW instead of on the first large
+ * snp_compress_batch / snp_frame_encode* call (see SNP_OPT_TABLE_PROBE_TRIES).  A service calls it once at start-up, before its own buffers
+ * crowd the device: the first request then pays nothing, and the placement search sees all of device memory.  With default options the search
+ * is the same bounded one a compress call would run (two workspaces' worth of candidates, < 1 s); with SNP_OPT_TABLE_PROBE_TRIES set it goes on
+ * looking for a third kind of memory as far as that budget allows (seconds: the driver clears fresh memory at ~27 ms per GiB).  Batches above
+ * 262 144 fragments run in slices, so that is the most it reserves.  Later, larger batches still grow the workspace on demand.
+ * SNP_OK, or SNP_ERR_DEVICE (snp_ctx_last_error says why). */
 snp_status snp_ctx_reserve_compress(snp_ctx* ctx, uint32_t nfragments);
 const char* snp_status_string(int status);
 const char* snp_version(void);
@@ -192,9 +197,13 @@ snp_status snp_frame_decode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* 
 
 /* Stream capture: snp_compress_batch, snp_decompress_batch, snp_crc32c_batch and snp_frame_encode_device only enqueue kernels, so they may be called while the context's
  * stream is being captured into a hipGraph and replayed later (the graph reads the device arrays as they are at replay time).  A captured call
- * queries, synchronises and allocates nothing; it therefore needs the context's workspaces to exist already -- make the same call once before
+ * queries, synchronises and allocates nothing; it therefore needs the workspaces to exist already -- make the same call once before
  * the capture (compress of >= 16 384 fragments: or snp_ctx_reserve_compress).  A call that would have to allocate during a capture returns
- * SNP_ERR_DEVICE (snp_ctx_last_error says so) and leaves the capture valid.  The host-pointer entry points synchronise and cannot be captured. */
+ * SNP_ERR_DEVICE (snp_ctx_last_error says so) and leaves the capture valid.  The host-pointer entry points synchronise and cannot be captured.
+ * LIFETIME: a captured graph holds the addresses of the workspaces it ran on.  From the first captured call on, the context (and the device's
+ * table pool) never frees a workspace it has handed out -- a later, larger call allocates a new one next to it -- until snp_ctx_destroy; a graph
+ * must not be replayed after its context is destroyed, nor concurrently with another context's compress on the same device (the event that
+ * orders borrowers of the table pool is not part of a capture). */
 
 /* nblocks independent inputs, each <= 65536 bytes (one fragment, SnappyCompressor.cs:40-80 loop body):
  * block b reads in[in_off[b] .. +in_len[b]) and writes  varint(in_len[b]) || CompressFragment  at

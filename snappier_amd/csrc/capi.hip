@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -63,6 +64,64 @@ inline u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 using snp_piece_search::PieceSearch;   // piece_search.h: why the workspace is made of pieces, and how they are chosen
 
 
+// ---- ONE hash-table workspace per DEVICE, shared by every context on it -----------------------------------------------------------------------
+// The lane compressor's tables are 64 KiB per fragment in flight (10.7 GB for 163 840): a context per caller thread must not mean a workspace per
+// caller thread, nor a placement search per context (the reference pools ONE table per compressor: HashTable.cs:22-55).  Contexts borrow the
+// device's workspace for the duration of one launch sequence: lock, make the stream wait for the previous borrower's event (a GPU-side wait: no
+// host thread blocks), launch, record the event, unlock.  A launch of >= 16 384 fragments fills the chip, so taking turns costs nothing that
+// running side by side would have gained.  The pool is built on first use, grows when a larger batch arrives (the old one is freed once its
+// last borrower's work is done -- or kept until the pool dies when a captured hipGraph may still hold its address), and dies with the device's
+// last context.
+struct TablePool {
+    std::mutex mu;
+    int users = 0;                                       // live contexts on this device
+    snp_table_pieces tp{};
+    void* plain = nullptr;                               // the one-allocation form (tp.p[0]) ...
+    size_t plain_cap = 0;
+    std::vector<void*> pieces;                           // ... or the searched form: up to 16 pieces (PieceSearch)
+    hipEvent_t last_use = nullptr;                       // recorded by the previous borrower after its launches
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    bool pinned = false;                                 // a borrower was capturing a hipGraph: no workspace this pool ever handed out is freed before the pool dies
+    std::vector<void*> retired;
+    uint64_t stats[4] = {0, 0, 0, 0};                    // chosen set's probe us, candidates, search us, most bytes the search held at once
+    uint64_t serves(u32 nblocks_cap_of = 0) const { (void)nblocks_cap_of; return pieces.empty() ? 0 : static_cast<uint64_t>(tp.piece_frags) * tp.n; }
+    void drain()
+    {
+        if (used && last_use) (void)hipEventSynchronize(last_use);
+    }
+    void drop_workspace()                                // callers hold mu
+    {
+        drain();
+        auto gone = [&](void* q) { if (!q) return; if (pinned) retired.push_back(q); else (void)hipFree(q); };
+        gone(plain);
+        for (void* q : pieces) gone(q);
+        plain = nullptr;
+        plain_cap = 0;
+        pieces.clear();
+        tp = snp_table_pieces{};
+    }
+    void destroy()                                       // the device's last context is gone
+    {
+        pinned = false;
+        drop_workspace();
+        for (void* q : retired) (void)hipFree(q);
+        retired.clear();
+        if (last_use) (void)hipEventDestroy(last_use);
+        last_use = nullptr;
+        used = false;
+    }
+};
+std::mutex g_pools_mu;
+TablePool* pool_of(int device)
+{
+    static TablePool* pools[64] = {};
+    std::lock_guard<std::mutex> g(g_pools_mu);
+    if (device < 0 || device >= 64) device = 0;
+    if (!pools[device]) pools[device] = new TablePool();
+    return pools[device];
+}
+
 }  // namespace
 
 struct snp_ctx {
@@ -73,7 +132,7 @@ struct snp_ctx {
     int fenced = 0;          // decompress kernel mode: bit 0 FENCED, bit 1 serial-only (debug knobs, see snp_ctx_create)
     int dec_lds = 0;         // dynamic LDS bytes per decode wavefront (occupancy throttle)
     int decode_layout = 0;   // 0 default (small blocks one per lane, the rest one per wavefront), 1 a debug front end is pinned
-    int table_tries = 16;    // workspaces' worth of candidate pieces the search for a >= 1 GiB hash-table workspace may hold at once (SNAPPIER_HIP_TABLE_TRIES /
+    int table_tries = 2;     // workspaces' worth of candidate pieces the search for a >= 1 GiB hash-table workspace may hold at once (SNAPPIER_HIP_TABLE_TRIES /
                              // SNP_OPT_TABLE_PROBE_TRIES; never more than fit in half of the free memory and under the byte cap; 1 = no search, one allocation).
                              // The search stops long before that when it can: piece_search.h
     uint64_t table_probe_max_bytes = 0;   // SNP_OPT_TABLE_PROBE_MAX_BYTES: cap on what the placement probe's candidates may occupy together (0 = half of free memory only)
@@ -95,7 +154,7 @@ struct snp_ctx {
     u32 win_gtab_min = 0xffffffffu;   // auto mode: window-kernel batches of at least this many fragments would keep their tables in global memory (SNAPPIER_HIP_WIN_GTAB_MIN);
                                       // never by default: measured +5 % only (36.4 vs 34.6 GB/s at 4 096-16 383 fragments -- the kernel turns texture-path-bound, profiles/r04k_pmc_window_kernel.txt)
     u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
-    DevBuf in, out, meta, work, tables, scan, small, redo, win_tables;
+    DevBuf in, out, meta, work, fragtab, scan, small, redo, win_tables;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
     uint64_t counters[6] = {0, 0, 0, 0, 0, 0};   // snp_ctx_counter
     bool table_tries_set = false;   // SNP_OPT_TABLE_PROBE_TRIES / SNAPPIER_HIP_TABLE_TRIES was given: the implicit in-call search honours it as is
@@ -205,7 +264,7 @@ struct snp_ctx {
     {
         hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(stream, &cap_st) != hipSuccess || cap_st != hipStreamCaptureStatusNone;
-        if (capturing) (void)hipGetLastError();
+        if (capturing) { (void)hipGetLastError(); was_captured = true; }
         return capturing;
     }
     u32* hint = nullptr;                                 // pinned: the previous batch's list length
@@ -266,7 +325,7 @@ struct snp_ctx {
         }
         const u32 kSlice = slice_fragments;   // (round 2 cut batches of small fragments into launches of 65 536; with the round-3 kernel 262 144 per launch is faster there too:
                                               //  256 B 43.5 -> 46.5 GB/s, 1 KiB 41.0 -> 49.0, profiles/r03p_small_compress_sweep.jsonl)
-        if (!ensure_tables(nblocks < kSlice ? nblocks : kSlice) || !ensure(small, 256, "hipMalloc(scalars)")) return false;
+        if (!ensure(small, 256, "hipMalloc(scalars)") || !borrow_tables(nblocks < kSlice ? nblocks : kSlice)) return false;
         // Launch shape by fragment size: 64 KiB fragments want 64 fragments per wavefront and 262 144 per launch, fragments of at most
         // 512 bytes 32 per wavefront and 65 536 per launch (256-byte blocks 36 -> 43.5 GB/s, 64-byte 31 -> 35; 1 KiB and up prefer the
         // former: profiles/r02w_small_block_compress.jsonl).  What the fragments are like is known only on the device, so the longest
@@ -280,9 +339,12 @@ struct snp_ctx {
             if (!check(snp_launch_compress_lanes(d_in, in_off + first, in_len + first, cnt, d_out, out_off + first,
                                                  out_len + first, status + first, variant, emit_varint, &tp,
                                                  static_cast<u32*>(small.p), stream, lanes_per_wave),
-                       "compress (lanes) launch"))
+                       "compress (lanes) launch")) {
+                return_tables();
                 return false;
+            }
         }
+        return_tables();
         if (!capturing && chint_ready() && !chint_pending) {            // this batch's longest fragment, for the next one
             if (hipMemcpyAsync(chint, small.p, 4, hipMemcpyDeviceToHost, stream) == hipSuccess && hipEventRecord(chint_ev, stream) == hipSuccess)
                 chint_pending = true;
@@ -315,7 +377,10 @@ struct snp_ctx {
             err = std::string(what) + ": a workspace would have to grow while the stream is being captured -- make the same call once before the capture (or snp_ctx_reserve_compress)";
             return false;
         }
-        if (b.p) (void)hipFree(b.p);
+        if (b.p) {
+            if (was_captured) kept.push_back(b.p);                      // a graph captured earlier may still hold this address: kept until snp_ctx_destroy
+            else (void)hipFree(b.p);
+        }
         b.p = nullptr;
         b.cap = 0;
         size_t want = bytes + bytes / 4 + 4096;
@@ -335,47 +400,90 @@ struct snp_ctx {
         return check(hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, stream), what) && check(hipStreamSynchronize(stream), what);
     }
 
-    // The hash-table workspace of the lane compressor (64 KiB per fragment in flight): one allocation below 1 GiB, above that up to 16 pieces
-    // chosen by PieceSearch (why: see there).
-    snp_table_pieces tp{};
-    std::vector<void*> piece_mem;                        // the pieces of a searched workspace (empty: tp.p[0] is tables.p)
-    void free_pieces()
+    // The hash-table workspace of the lane compressor (64 KiB per fragment in flight) belongs to the DEVICE (TablePool above): one allocation below
+    // 1 GiB, above that up to 16 pieces chosen by PieceSearch (why: see there).  A context borrows it per launch sequence.
+    TablePool* pool = nullptr;
+    snp_table_pieces tp{};                               // the borrowed view (valid between borrow_tables and return_tables)
+    bool borrowed = false;
+    // Borrows the device's workspace for batches of up to nblocks fragments: builds or grows it if need be (thorough: snp_ctx_reserve_compress),
+    // orders this context's stream behind the previous borrower.  return_tables() must follow the launches.
+    bool was_captured = false;                           // a call of this context ran under stream capture: no workspace is freed before snp_ctx_destroy
+    std::vector<void*> kept;
+    DevBuf own_tables;                                   // SNP_OPT_TABLE_PROBE_TRIES = 1: a plain one-allocation workspace of this context's own (no pool, no search)
+    bool borrow_tables(u32 nblocks, bool thorough = false)
     {
-        for (void* q : piece_mem) (void)hipFree(q);
-        piece_mem.clear();
-        tp = snp_table_pieces{};
+        if (table_tries_set && table_tries == 1) {
+            const size_t bytes = snp_compress_lanes_workspace(nblocks);
+            if (bytes > own_tables.cap) {
+                if (stream_is_capturing()) { err = "hash-table workspace: it would have to grow while the stream is being captured"; return false; }
+                (void)hipStreamSynchronize(stream);
+                if (own_tables.p) { if (was_captured) kept.push_back(own_tables.p); else (void)hipFree(own_tables.p); }
+                own_tables = DevBuf{};
+                if (!check(hipMalloc(&own_tables.p, bytes + 4096), "hipMalloc(hash tables)")) { own_tables.p = nullptr; return false; }
+                own_tables.cap = bytes + 4096;
+            }
+            tp = snp_table_pieces{};
+            tp.p[0] = static_cast<u32*>(own_tables.p);
+            tp.piece_frags = 0xffffffc0u;
+            tp.n = 1;
+            counters[2] = counters[3] = counters[4] = counters[5] = 0;
+            return true;                                 // (borrowed stays false: return_tables has nothing to do)
+        }
+        TablePool& P = *pool;
+        P.mu.lock();
+        const bool capturing = stream_is_capturing();
+        if (!build_tables(P, nblocks, thorough, capturing)) { P.mu.unlock(); return false; }
+        if (capturing) {
+            P.pinned = true;                             // the graph keeps the address: nothing this pool handed out is freed before the pool dies
+        } else if (P.used && P.last_stream != stream) {
+            if (!check(hipStreamWaitEvent(stream, P.last_use, 0), "hipStreamWaitEvent(table pool)")) { P.mu.unlock(); return false; }
+        }
+        tp = P.tp;
+        counters[2] = P.stats[0]; counters[3] = P.stats[1]; counters[4] = P.stats[2]; counters[5] = P.stats[3];
+        borrowed = true;
+        return true;
     }
-    bool ensure_tables(u32 nblocks, bool thorough = false)
+    void return_tables()
+    {
+        if (!borrowed) return;
+        TablePool& P = *pool;
+        if (!stream_is_capturing()) {                    // (a captured launch is ordered by its graph; see INTEGRATION.md "Inside a hipGraph")
+            if (!P.last_use && hipEventCreateWithFlags(&P.last_use, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); P.last_use = nullptr; }
+            if (P.last_use && hipEventRecord(P.last_use, stream) == hipSuccess) { P.used = true; P.last_stream = stream; }
+            else { (void)hipGetLastError(); (void)hipStreamSynchronize(stream); P.used = false; }
+        }
+        borrowed = false;
+        P.mu.unlock();
+    }
+    // (callers hold P.mu)
+    bool build_tables(TablePool& P, u32 nblocks, bool thorough, bool capturing)
     {
         const size_t bytes = snp_compress_lanes_workspace(nblocks);
-        if (!piece_mem.empty() && static_cast<uint64_t>(nblocks) <= static_cast<uint64_t>(tp.piece_frags) * tp.n) return true;
-        if ((!piece_mem.empty() || bytes > tables.cap) && stream_is_capturing()) {   // (as in ensure(): no allocation, no search, no synchronisation inside a capture)
+        if (!P.pieces.empty() && static_cast<uint64_t>(nblocks) <= static_cast<uint64_t>(P.tp.piece_frags) * P.tp.n) return true;
+        if (P.pieces.empty() && P.plain && bytes <= P.plain_cap) return true;
+        if (capturing) {                                 // (as in ensure(): no allocation, no search, no synchronisation inside a capture)
             err = "hash-table workspace: it would have to be built while the stream is being captured -- call snp_ctx_reserve_compress (or make the same call once) before the capture";
             return false;
         }
-        if (!piece_mem.empty()) free_pieces();
-        // The search inside a compress CALL is conservative unless the caller configured it: two workspaces' worth of candidates (one
-        // transient extra workspace, a few hundred ms) -- a request must not take seconds or crowd a shared device.  The thorough
-        // search (SNP_OPT_TABLE_PROBE_TRIES workspaces' worth, default 16) belongs to snp_ctx_reserve_compress, a service's start-up.
-        const int tries = (thorough || table_tries_set) ? table_tries : (table_tries < 2 ? table_tries : 2);
-        if (bytes < (1ull << 30) || tries <= 1 || bytes <= tables.cap) {
-            if (bytes > tables.cap) {
-                if (tables.p) (void)hipFree(tables.p);
-                tables = DevBuf{};
-                // (a GiB-sized workspace gets no growth slack: 25 % of 10.7 GB is 2.7 GB that nothing ever uses)
-                const size_t want = bytes >= (1ull << 30) ? bytes + 4096 : bytes + bytes / 4 + 4096;
-                if (!check(hipMalloc(&tables.p, want), "hipMalloc(hash tables)")) { tables.p = nullptr; return false; }
-                tables.cap = want;
-                counters[2] = counters[3] = counters[4] = counters[5] = 0;
-            }
-            tp = snp_table_pieces{};
-            tp.p[0] = static_cast<u32*>(tables.p);
-            tp.piece_frags = 0xffffffc0u;
-            tp.n = 1;
+        // How far the placement search may go.  By default it holds at most TWO workspaces' worth of candidate pieces at once (one transient extra
+        // workspace, a few hundred ms) and never more than half of what is free: a library must not take seconds or crowd a shared device on its own
+        // account.  A caller that wants the thorough search -- device memory comes in regions of three kinds tens of GiB long,
+        // and the third may lie 150 GB of allocations away -- says so: SNP_OPT_TABLE_PROBE_TRIES workspaces' worth (up to 24), within
+        // SNP_OPT_TABLE_PROBE_MAX_BYTES, at start-up through snp_ctx_reserve_compress.
+        const int tries = table_tries_set ? table_tries : 2;
+        P.drop_workspace();                              // (waits for the previous borrower; a pinned pool keeps the old memory until it dies)
+        P.stats[0] = P.stats[1] = P.stats[2] = P.stats[3] = 0;
+        if (bytes < (1ull << 30) || tries <= 1) {
+            // (a GiB-sized workspace gets no growth slack: 25 % of 10.7 GB is 2.7 GB that nothing ever uses)
+            const size_t want = bytes >= (1ull << 30) ? bytes + 4096 : bytes + bytes / 4 + 4096;
+            if (!check(hipMalloc(&P.plain, want), "hipMalloc(hash tables)")) { P.plain = nullptr; return false; }
+            P.plain_cap = want;
+            P.tp = snp_table_pieces{};
+            P.tp.p[0] = static_cast<u32*>(P.plain);
+            P.tp.piece_frags = 0xffffffc0u;
+            P.tp.n = 1;
             return true;
         }
-        if (tables.p) (void)hipFree(tables.p);           // (a small workspace of earlier calls: the pieces replace it)
-        tables = DevBuf{};
         PieceSearch ps{};
         // capacity = the batch + 1/16 of slack (at most one slice): a later batch of slightly more fragments must not repeat the search
         const uint64_t with_slack = static_cast<uint64_t>(nblocks) + nblocks / 16u;
@@ -384,17 +492,16 @@ struct snp_ctx {
         const size_t piece_bytes = static_cast<size_t>(piece_frags) * 65536u;
         ps.n = (cap_frags + piece_frags - 1) / piece_frags;
         ps.piece_gib = piece_bytes / 1073741824.0;
-        // snp_ctx_reserve_compress (thorough) with the default option: as many candidates as memory allows.  The kinds lie in runs of ~100 pieces in
-        // allocation order; processes were seen whose third kind began at candidate 176 and at 208, and one where 216 (half of free memory) did not
-        // reach it (bench 94 instead of 99.5 GB/s, profiles/r04ag_search_reach.txt) -- so the thorough search may hold three quarters of what is free.
-        const bool reach = thorough && !table_tries_set;
-        ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(reach && tries < 24 ? 24 : tries);   // (24 workspaces' worth: 384 pieces, more than three quarters of 288 GB hold at 163 840 fragments)
+        ps.max_cand = static_cast<size_t>(ps.n) * static_cast<size_t>(tries);
         ps.dbg = SNP_GETENV("SNAPPIER_HIP_DEBUG") != nullptr;
-        if (thorough) ps.patience = 64;                                       // snp_ctx_reserve_compress: the caller has time -- look for a third kind as far as max_cand allows
+        if (thorough && table_tries_set) ps.patience = 64;                   // the caller asked for it and has time: look for a third kind as far as max_cand allows
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {                // the candidates coexist: stay within half (thorough: three quarters) of what is free
-            size_t room = reach ? free_b / 4 * 3 : free_b / 2;               // ... and within the caller's byte cap (SNP_OPT_TABLE_PROBE_MAX_BYTES)
-            if (table_probe_max_bytes && table_probe_max_bytes < room) room = static_cast<size_t>(table_probe_max_bytes);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {                // the candidates coexist: never more than half of what is free,
+            size_t room = free_b / 2;                                         // ... unless the caller set a byte cap of its own (SNP_OPT_TABLE_PROBE_MAX_BYTES),
+            if (table_probe_max_bytes) {                                      // which is honoured up to 7/8 of what is free: an explicit decision, not a default
+                room = static_cast<size_t>(table_probe_max_bytes);
+                if (room > free_b / 8 * 7) room = free_b / 8 * 7;
+            }
             if (room / piece_bytes < ps.max_cand) ps.max_cand = room / piece_bytes;
         }
         if (ps.max_cand < ps.n) ps.max_cand = ps.n;                          // the workspace itself is not optional
@@ -423,16 +530,16 @@ struct snp_ctx {
             return false;
         }
         std::vector<char> used(cand.size(), 0);
-        tp = snp_table_pieces{};
-        for (u32 i = 0; i < ps.n; ++i) { tp.p[i] = cand[set[i]]; used[set[i]] = 1; piece_mem.push_back(cand[set[i]]); }
-        tp.piece_frags = piece_frags;
-        tp.n = ps.n;
+        P.tp = snp_table_pieces{};
+        for (u32 i = 0; i < ps.n; ++i) { P.tp.p[i] = cand[set[i]]; used[set[i]] = 1; P.pieces.push_back(cand[set[i]]); }
+        P.tp.piece_frags = piece_frags;
+        P.tp.n = ps.n;
         for (size_t k = 0; k < cand.size(); ++k)
             if (!used[k]) (void)hipFree(cand[k]);
-        counters[2] = ms < 1e6f ? static_cast<uint64_t>(ms * 1000.0f) : 0;    // (a probe that failed reports 1e30: the set then is whatever the arithmetic picked)
-        counters[3] = static_cast<uint64_t>(cand.size());
-        counters[4] = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_search).count());
-        counters[5] = static_cast<uint64_t>(cand.size()) * piece_bytes;       // most bytes the search held at once (all candidates coexist until it ends)
+        P.stats[0] = ms < 1e6f ? static_cast<uint64_t>(ms * 1000.0f) : 0;     // (a probe that failed reports 1e30: the set then is whatever the arithmetic picked)
+        P.stats[1] = static_cast<uint64_t>(cand.size());
+        P.stats[2] = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_search).count());
+        P.stats[3] = static_cast<uint64_t>(cand.size()) * piece_bytes;        // most bytes the search held at once (all candidates coexist until it ends)
         return true;
     }
     bool use_device() { return check(hipSetDevice(device), "hipSetDevice"); }
@@ -498,6 +605,7 @@ struct DevGuard {
     {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         ok = prev == dev || c->use_device();
+        if (ok && !c->was_captured && c->stream) (void)c->stream_is_capturing();   // (latches was_captured: from then on no workspace is freed before destroy)
     }
     ~DevGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
 };
@@ -522,6 +630,11 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SNP_ERR_DEVICE; }
         c->own_stream = true;
+    }
+    c->pool = pool_of(device);
+    {
+        std::lock_guard<std::mutex> g(c->pool->mu);
+        ++c->pool->users;
     }
     // debug knobs: SNAPPIER_HIP_FENCED=1 drains vmcnt before reading young output; SNAPPIER_HIP_DECODE=serial
     // disables the token-parallel front end of the decompressor (bit 1 of the kernel mode)
@@ -566,7 +679,7 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     // SNAPPIER_HIP_PARALLEL_MIN=<bytes>: declared length from which snp_try_decompress splits ONE block into 64 KiB
     // fragments decoded in parallel (tag_index.hip); 0 = always one wavefront per block
     const char* tt = SNP_GETENV("SNAPPIER_HIP_TABLE_TRIES");
-    if (tt) { c->table_tries = atoi(tt) < 1 ? 1 : atoi(tt) > 16 ? 16 : atoi(tt); c->table_tries_set = true; }
+    if (tt) { c->table_tries = atoi(tt) < 1 ? 1 : atoi(tt) > 24 ? 24 : atoi(tt); c->table_tries_set = true; }
     const char* pm = SNP_GETENV("SNAPPIER_HIP_PARALLEL_MIN");
     if (pm) c->par_min = static_cast<u32>(strtoul(pm, nullptr, 10));
     *out_ctx = c;
@@ -581,7 +694,9 @@ snp_status snp_ctx_reserve_compress(snp_ctx* c, uint32_t nfragments)
     if (nfragments == 0) return SNP_OK;
     DevGuard dg(c);
     if (!dg.ok) return SNP_ERR_DEVICE;
-    return c->ensure_tables(nfragments < c->slice_fragments ? nfragments : c->slice_fragments, true) ? SNP_OK : SNP_ERR_DEVICE;
+    if (!c->borrow_tables(nfragments < c->slice_fragments ? nfragments : c->slice_fragments, true)) return SNP_ERR_DEVICE;
+    c->return_tables();
+    return SNP_OK;
 }
 
 snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
@@ -611,7 +726,7 @@ snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
             c->win_max = static_cast<u32>(v);
             return SNP_OK;
         case SNP_OPT_TABLE_PROBE_TRIES:
-            if (v < 1 || v > 16) return SNP_ERR_BAD_ARG;
+            if (v < 1 || v > 24) return SNP_ERR_BAD_ARG;
             c->table_tries = static_cast<int>(v);
             c->table_tries_set = true;
             return SNP_OK;
@@ -666,9 +781,13 @@ void snp_ctx_destroy(snp_ctx* c)
     {
         DevGuard dg(c);
         (void)hipStreamSynchronize(c->stream);
-        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->tables, &c->scan, &c->small, &c->redo, &c->win_tables})
+        for (DevBuf* b : {&c->in, &c->out, &c->meta, &c->work, &c->fragtab, &c->scan, &c->small, &c->redo, &c->win_tables, &c->own_tables})
             if (b->p) (void)hipFree(b->p);
-        c->free_pieces();
+        for (void* q : c->kept) (void)hipFree(q);
+        if (c->pool) {                                    // the device's last context takes the table pool with it
+            std::lock_guard<std::mutex> g(c->pool->mu);
+            if (--c->pool->users == 0) c->pool->destroy();
+        }
         if (c->order_ev) (void)hipEventDestroy(c->order_ev);
         if (c->hint_ev) (void)hipEventDestroy(c->hint_ev);
         if (c->chint_ev) (void)hipEventDestroy(c->chint_ev);
@@ -1084,9 +1203,9 @@ snp_status decompress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uin
             const u32 nf = (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
             // fragment table: in_off, out_off (u64) ; in_len, out_cap, skip, out_len (u32) ; status (i32)
             if (!c->ensure(c->work, static_cast<size_t>(nent) * 8 + 16, "hipMalloc(tag index)") ||
-                !c->ensure(c->tables, static_cast<size_t>(nf) * (8 * 2 + 4 * 5), "hipMalloc(fragment table)"))
+                !c->ensure(c->fragtab, static_cast<size_t>(nf) * (8 * 2 + 4 * 5), "hipMalloc(fragment table)"))
                 return SNP_ERR_DEVICE;
-            u64* f_in_off = static_cast<u64*>(c->tables.p);
+            u64* f_in_off = static_cast<u64*>(c->fragtab.p);
             u64* f_out_off = f_in_off + nf;
             u32* f_in_len = reinterpret_cast<u32*>(f_out_off + nf);
             u32* f_out_cap = f_in_len + nf;

@@ -367,63 +367,81 @@ def test_crc32c_table_free_kernel_equals_the_table_kernel_and_the_oracle():
 
 
 def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
-    """A lane-compressor batch whose hash-table workspace is >= 1 GiB runs on up to 16 separately allocated pieces picked by the
-    placement search (capi.hip, PieceSearch); below that, with SNP_OPT_TABLE_PROBE_TRIES = 1, or when the byte cap leaves no room for
-    spare candidates, on plain allocations.  All of them must return the oracle's bytes: every block compared by length and CRC across
-    the contexts, the blocks either side of every piece boundary (and the ragged tail) byte for byte against the oracle; a second,
-    larger batch makes the searched workspace grow (pieces freed, search repeated)."""
+    """A lane-compressor batch whose hash-table workspace is >= 1 GiB runs on up to 16 separately allocated pieces picked by the placement
+    search (capi.hip, TablePool / PieceSearch) -- the DEVICE's workspace, which every context borrows; with SNP_OPT_TABLE_PROBE_TRIES = 1 on a
+    plain allocation of the context's own; when the byte cap leaves no room for spare candidates, on unsearched pieces.  All of them must
+    return the oracle's bytes: every block compared by length and CRC across the forms, the blocks either side of every piece boundary (and
+    the ragged tail) byte for byte against the oracle; a second, larger batch makes the pool grow (pieces freed, bounded search repeated)."""
     N = S._native
+    import gc
     from snappier_amd import datagen as SD
+    gc.collect()                                                       # (contexts of earlier tests: the device's pool dies with the last of them)
     html = read_testdata("html")
-    results = {}
-    for nb in (20001, 36000):                                          # 1.3 GB and 2.4 GB of tables: 16 pieces of 1280 / 2304 fragments
+    sizes = (20001, 36000)                                             # 1.3 GB and 2.4 GB of tables: 16 pieces of 1344 / 2432 fragments
+
+    def inputs(nb):
         raw = SD.html_like_blocks(html, 7, nb, "cuda")
         lens = torch.full((nb,), 65536, dtype=torch.int32, device="cuda")
         lens[-1] = 777
         lens[nb // 2] = 0
         off = torch.arange(nb, dtype=torch.int64, device="cuda") * 65536
-        sigs = []
-        for name in ("searched", "one_allocation", "capped"):
-            cd = results.setdefault(name, SB.BlockCodec(0, O.HASH_CRC32C))
-            if name == "one_allocation":
-                cd.ctx.set_option(N.OPT_TABLE_PROBE_TRIES, 1)
-            if name == "capped":
-                cd.ctx.set_option(N.OPT_TABLE_PROBE_MAX_BYTES, 1 << 30)
-            cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, 2)
-            if name == "searched" and nb == 20001:                     # snp_ctx_reserve_compress: the search runs now, the call below finds the workspace built
-                cd.ctx.reserve_compress(nb)
-                searched_at_reserve = cd.ctx.counter(3)
-                assert searched_at_reserve >= 32 and cd.ctx.counter(2) > 0
-                assert cd.ctx.counter(4) > 0 and cd.ctx.counter(5) >= searched_at_reserve * 1280 * 65536   # search wall time (us), bytes held at once
-            out, out_off, out_len, st = cd.compress(raw, off, lens)
-            if name == "searched" and nb == 20001:
-                assert cd.ctx.counter(3) == searched_at_reserve, "the compress call searched again after snp_ctx_reserve_compress"
-            torch.cuda.synchronize()
-            assert int((st != 0).sum()) == 0
-            crcs = cd.crc32c(out, out_off, out_len)
-            sigs.append((name, out_len.cpu().numpy(), crcs.cpu().numpy()))
-            if name == "searched":
-                assert cd.ctx.counter(3) >= 32 and cd.ctx.counter(2) > 0, "the search did not run"
-                if nb == 36000:                                         # this workspace grew inside a compress CALL: the conservative search (two workspaces' worth)
-                    assert cd.ctx.counter(3) <= 32, "the in-call search held more than two workspaces' worth of candidates"
-                piece = ((nb + nb // 16 + 15) // 16 + 63) // 64 * 64        # capacity = the batch + 1/16 of slack (capi.hip, ensure_tables)
-                check = sorted({b for k in range(1, 16) for b in (k * piece - 1, k * piece) if b < nb} | {0, nb // 2, nb - 2, nb - 1})
-                idx = torch.tensor(check, device="cuda")
-                sub = torch.cat([raw[int(off[b]): int(off[b]) + int(lens[b])] for b in check]).cpu().numpy()
-                sub_len = lens[idx].cpu().numpy().astype(np.uint32)
-                sub_off = np.concatenate([[0], np.cumsum(sub_len[:-1], dtype=np.uint64)]).astype(np.uint64)
-                ref, ref_off, ref_len, ref_st = O.compress_batch(sub, sub_off, sub_len, O.HASH_CRC32C, THREADS)
-                outh_len = out_len[idx].cpu().numpy()
-                assert (ref_st == 0).all() and (outh_len == ref_len).all()
-                for j, b in enumerate(check):
-                    got = out[int(out_off[b]): int(out_off[b]) + int(outh_len[j])].cpu().numpy()
-                    assert np.array_equal(got, ref[int(ref_off[j]): int(ref_off[j]) + int(ref_len[j])]), f"block {b} (piece boundary) of {nb}"
-            else:
-                assert cd.ctx.counter(3) in (0, 16), name          # no spare candidates: nothing to search
-        for name, l, c in sigs[1:]:
-            assert (l == sigs[0][1]).all() and (c == sigs[0][2]).all(), f"{name} differs from the searched workspace at {nb} blocks"
+        return raw, off, lens
+
+    def signature(cd, raw, off, lens):
+        out, out_off, out_len, st = cd.compress(raw, off, lens)
+        torch.cuda.synchronize()
+        assert int((st != 0).sum()) == 0
+        crcs = cd.crc32c(out, out_off, out_len)
+        return out, out_off, out_len, (out_len.cpu().numpy(), crcs.cpu().numpy())
+
+    # 1. a pool built under a byte cap that leaves no room for spare candidates (no other context alive: the pool is this context's to build)
+    capped = {}
+    for nb in sizes:
+        raw, off, lens = inputs(nb)
+        cd = SB.BlockCodec(0, O.HASH_CRC32C)
+        cd.ctx.set_option(N.OPT_TABLE_PROBE_MAX_BYTES, 1 << 30)
+        cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, 2)
+        *_x, capped[nb] = signature(cd, raw, off, lens)
+        assert cd.ctx.counter(3) in (0, 16), "capped: nothing to search"
+        cd.ctx.close()                                                  # the device's last context: the pool goes with it
         del raw
-    log_session(test="hash_table_workspace_in_pieces", blocks=[20001, 36000], contexts=["searched", "one_allocation", "capped"], result="all equal")
+    # 2. the searched pool (default budget: two workspaces' worth of candidates), a second context that borrows it, and a private plain workspace
+    searched, borrower, plain = SB.BlockCodec(0, O.HASH_CRC32C), SB.BlockCodec(0, O.HASH_CRC32C), SB.BlockCodec(0, O.HASH_CRC32C)
+    plain.ctx.set_option(N.OPT_TABLE_PROBE_TRIES, 1)
+    for cd in (searched, borrower, plain):
+        cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, 2)
+    for nb in sizes:
+        raw, off, lens = inputs(nb)
+        if nb == sizes[0]:                                              # snp_ctx_reserve_compress: the search runs now, the call below finds the pool built
+            searched.ctx.reserve_compress(nb)
+            at_reserve = searched.ctx.counter(3)
+            assert 16 < at_reserve <= 32 and searched.ctx.counter(2) > 0, f"the default search holds at most two workspaces' worth of candidates: {at_reserve}"
+            piece0 = ((nb + nb // 16 + 15) // 16 + 63) // 64 * 64
+            assert searched.ctx.counter(4) > 0 and searched.ctx.counter(5) == at_reserve * piece0 * 65536   # search wall time (us), bytes held at once
+        out, out_off, out_len, sig = signature(searched, raw, off, lens)
+        if nb == sizes[0]:
+            assert searched.ctx.counter(3) == at_reserve, "the compress call searched again after snp_ctx_reserve_compress"
+        assert 16 < searched.ctx.counter(3) <= 32 and searched.ctx.counter(2) > 0, "the search did not run (or went beyond its default budget)"
+        piece = ((nb + nb // 16 + 15) // 16 + 63) // 64 * 64            # capacity = the batch + 1/16 of slack (capi.hip, build_tables)
+        check = sorted({b for k in range(1, 16) for b in (k * piece - 1, k * piece) if b < nb} | {0, nb // 2, nb - 2, nb - 1})
+        idx = torch.tensor(check, device="cuda")
+        sub = torch.cat([raw[int(off[b]): int(off[b]) + int(lens[b])] for b in check]).cpu().numpy()
+        sub_len = lens[idx].cpu().numpy().astype(np.uint32)
+        sub_off = np.concatenate([[0], np.cumsum(sub_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+        ref, ref_off, ref_len, ref_st = O.compress_batch(sub, sub_off, sub_len, O.HASH_CRC32C, THREADS)
+        outh_len = out_len[idx].cpu().numpy()
+        assert (ref_st == 0).all() and (outh_len == ref_len).all()
+        for j, b in enumerate(check):
+            got = out[int(out_off[b]): int(out_off[b]) + int(outh_len[j])].cpu().numpy()
+            assert np.array_equal(got, ref[int(ref_off[j]): int(ref_off[j]) + int(ref_len[j])]), f"block {b} (piece boundary) of {nb}"
+        *_x, sig_b = signature(borrower, raw, off, lens)
+        assert borrower.ctx.counter(3) == searched.ctx.counter(3) and borrower.ctx.counter(5) == searched.ctx.counter(5), "the second context built a workspace of its own"
+        *_x, sig_p = signature(plain, raw, off, lens)
+        assert plain.ctx.counter(3) == 0, "SNP_OPT_TABLE_PROBE_TRIES = 1 searched"
+        for name, (l, c) in (("borrower", sig_b), ("one allocation", sig_p), ("capped", capped[nb])):
+            assert (l == sig[0]).all() and (c == sig[1]).all(), f"{name} differs from the searched workspace at {nb} blocks"
+        del raw
+    log_session(test="hash_table_workspace_in_pieces", blocks=list(sizes), contexts=["capped", "searched", "borrower", "one_allocation"], result="all equal")
 
 
 @pytest.mark.parametrize("variant", [O.HASH_CRC32C, O.HASH_MUL])

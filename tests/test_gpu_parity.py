@@ -1044,3 +1044,55 @@ def test_frame_decode_takes_chunks_beyond_64_kib_like_the_reference():
         torch.cuda.synchronize()
         assert res.tolist() == [len(ref), 0]
         assert_same("device header walk", out[: len(ref)].cpu().numpy().tobytes(), ref)
+
+
+def test_two_threads_share_the_devices_table_pool():
+    """the lane compressor's hash-table workspace belongs to the device.  Two caller threads, a context each, compress
+    >= 16 384 fragments each at the same time: the bytes equal the oracle's, and the library allocates ONE workspace (plus its bounded
+    search: at most a second workspace's worth of candidates, transiently), not one per context."""
+    import gc
+    import threading
+    gc.collect()                                                            # (contexts of earlier tests: the device's pool dies with the last of them)
+    nb = 20480                                                              # 1.25 GiB of tables per launch: the searched (pieces) form
+    html = read_testdata("html")
+    raws = [SD.html_like_blocks(html, 1000 * t, nb, "cuda") for t in range(2)]
+    cds = [SB.BlockCodec(0, O.HASH_CRC32C) for _ in range(2)]
+    outs = [torch.empty(nb * cds[0].comp_stride, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    out_off = torch.arange(nb, dtype=torch.int64, device="cuda") * cds[0].comp_stride
+    in_off, in_len = cds[0].uniform_layout(nb)
+    cds[0].crc32c(raws[0], in_off, in_len)                                  # (first-use allocations that are not the tables)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()                                    # every torch buffer exists: what disappears from here on is the library's
+    results, errors = [None, None], []
+    low_water = [free0]
+
+    def work(t):
+        try:
+            cd = cds[t]
+            for _ in range(3):
+                _o, _oo, out_len, status = cd.compress(raws[t], in_off, in_len, out=outs[t], out_off=out_off)
+                low_water[0] = min(low_water[0], torch.cuda.mem_get_info()[0])
+            cd.ctx.synchronize()
+            results[t] = (out_len.cpu().numpy(), status.cpu().numpy())
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors
+    oo = out_off.cpu().numpy()
+    for t in range(2):
+        out_len, status = results[t]
+        assert (status == 0).all()
+        raw, out = raws[t].cpu().numpy(), outs[t].cpu().numpy()
+        for b in list(range(0, nb, 997)) + [nb - 1]:
+            assert_same(f"thread {t} block {b}", out[oo[b]:oo[b] + out_len[b]].tobytes(),
+                        O.compress(raw[b * 65536:(b + 1) * 65536].tobytes(), O.HASH_CRC32C))
+    tables = nb * 65536
+    used = free0 - low_water[0]
+    # one workspace (+ 1/16 slack) and, while the search runs, at most a second one's worth of candidates; two private workspaces with a search
+    # each would have taken more than twice that
+    assert used < 2.4 * tables + (256 << 20), (used / 2**30, tables / 2**30)
+    assert cds[0].ctx.counter(5) == cds[1].ctx.counter(5) and cds[0].ctx.counter(3) == cds[1].ctx.counter(3)   # the same pool's search, not one each
+    assert cds[0].ctx.counter(3) <= 32, "the default search holds at most two workspaces' worth of candidates"
