@@ -35,7 +35,7 @@ public enum SnpOption : int
     ParallelDecodeMin = 8,
     Fenced = 9,
     DecodeLeftovers = 10,
-    CrcTableFree = 11,          // CRC-32C kernel: 0 = three LDS tables (default, 5.8 TB/s), 1 = table-free (1.7 TB/s), 2 = four 8-bit tables (round 3)
+    CrcKernel = 11,          // CRC-32C kernel: 0 = three LDS tables (default, 5.8 TB/s), 1 = table-free (1.7 TB/s), 2 = four 8-bit tables (round 3)
 }
 
 public enum SnpHash : int

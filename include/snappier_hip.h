@@ -130,10 +130,11 @@ typedef enum snp_option {
     SNP_OPT_PARALLEL_DECODE_MIN = 8,    /* snp_try_decompress: declared bytes from which ONE block is decoded a wavefront per 64 KiB fragment (0 = never; default 262144) */
     SNP_OPT_FENCED = 9,                 /* 1 (default): a wavefront drains its stores before it reads output bytes it wrote itself; 0 relies on in-order vector memory */
     SNP_OPT_DECODE_LEFTOVERS = 10,      /* blocks the pre-pass leaves over: 0 (default) by the previous batch, 1 one workgroup per block, 2 a list for persistent wavefronts */
-    /* CRC-32C kernel: 0 (default) the GF(2) shift map sliced 11 + 11 + 10 bits out of three tables in LDS (5.8 TB/s); 1 = TABLE-FREE, the
+    /* Which CRC-32C kernel runs (named SNP_OPT_CRC_TABLE_FREE until round 4; same number): 0 (default) the GF(2) shift map sliced
+     * 11 + 11 + 10 bits out of three tables in LDS (5.6-5.9 TB/s; batches too small to amortise the table copy take form 2); 1 = TABLE-FREE, the
      * map applied bit by bit in registers (1.7 TB/s: VALU-bound; gfx950 has neither a CRC instruction nor a carry-less multiply);
      * 2 = round 3's four 256-entry tables (5.3 TB/s).  Same results. */
-    SNP_OPT_CRC_TABLE_FREE = 11
+    SNP_OPT_CRC_KERNEL = 11
 } snp_option;
 snp_status snp_ctx_set_option(snp_ctx* ctx, int option, int64_t value);
 snp_status snp_ctx_get_option(const snp_ctx* ctx, int option, int64_t* out_value);
@@ -227,8 +228,8 @@ snp_status snp_decompress_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t*
                                 uint32_t nblocks, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap,
                                 uint32_t* out_len, int32_t* status);
 
-/* CRC-32C (optionally masked) of nblocks independent byte ranges; wave-parallel (each lane folds its dwords with a
- * GF(2)-linear shift map applied sliced-by-8 from four 256-entry tables in LDS, crc32c.hip). */
+/* CRC-32C (optionally masked) of nblocks independent byte ranges; wave-parallel (each lane folds its dwords with a GF(2)-linear
+ * shift map; which form of the map runs is SNP_OPT_CRC_KERNEL: by default sliced 11 + 11 + 10 bits out of three LDS tables, crc32c.hip). */
 snp_status snp_crc32c_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
                             uint32_t nblocks, int masked, uint32_t* out_crc);
 

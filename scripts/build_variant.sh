@@ -5,6 +5,8 @@
 #     LAB=1 scripts/build_variant.sh lab                   the LAB library: lab/decompress_r04.hip in place of decompress.hip (every decoder front
 #                                                          end that was measured and lost), and -DSNAPPIER_HIP_DEBUG_ENV on every source (the
 #                                                          SNAPPIER_HIP_* knobs act: the product library reads no environment)
+#     LAB=1 CLAB=1 SRC=compress_lanes.hip scripts/build_variant.sh clablate -DSNP_CL_ABLATE_RT=1
+#                                                          ... with lab/compress_lanes_r04.hip (the lane compressor with its timing-only ablations)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
@@ -15,9 +17,12 @@ if [ "$LAB" = 1 ]; then OBJ=${OBJ}_lab; fi
 mkdir -p $OBJ snappier_amd/variants
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fconstexpr-steps=100000000 -Wno-sometimes-uninitialized -Wno-unused-function"
 DEC=decompress
+CL=compress_lanes
 if [ "$LAB" = 1 ]; then FLAGS="$FLAGS -DSNAPPIER_HIP_DEBUG_ENV"; DEC=lab/decompress_r04; fi
+if [ "${CLAB:-0}" = 1 ]; then CL=lab/compress_lanes_r04; fi
 if [ "$SRC" = decompress.hip ] && [ "$LAB" = 1 ]; then SRC=lab/decompress_r04.hip; fi
-FILES="decode_chains $DEC decompress_small tag_index compress_lanes compress_win crc32c framing frame_scan capi"
+if [ "$SRC" = compress_lanes.hip ] && [ "${CLAB:-0}" = 1 ]; then SRC=lab/compress_lanes_r04.hip; fi
+FILES="decode_chains $DEC decompress_small tag_index $CL compress_win crc32c framing frame_scan capi"
 newest_header=$(ls -t snappier_amd/csrc/*.h include/*.h | head -1)
 for f in $FILES; do
   o=$OBJ/$(basename $f).o

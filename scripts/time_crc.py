@@ -12,8 +12,8 @@ html = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "te
 cd = SB.BlockCodec(0, S.HASH_CRC32C)
 raw = SD.html_like_blocks(html, 0, nb, "cuda")
 in_off, in_len = cd.uniform_layout(nb)
-table_free = int(os.environ.get("TABLE_FREE", "0"))      # SNP_OPT_CRC_TABLE_FREE: 0 default (three tables), 1 table-free, 2 four 8-bit tables
-cd.ctx.set_option(S._native.OPT_CRC_TABLE_FREE, table_free)
+table_free = int(os.environ.get("TABLE_FREE", "0"))      # SNP_OPT_CRC_KERNEL: 0 default (three tables), 1 table-free, 2 four 8-bit tables
+cd.ctx.set_option(S._native.OPT_CRC_KERNEL, table_free)
 ms = []
 for i in range(int(os.environ.get('REPS', '12'))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

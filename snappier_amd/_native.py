@@ -24,7 +24,7 @@ BLOCK_SIZE = 65536
 MAX_BLOCK_COMPRESSED = 76491
 # snp_option (include/snappier_hip.h)
 (OPT_DECODE_LAYOUT, OPT_SMALL_BLOCK_MAX, OPT_SMALL_BLOCK_MIN_BATCH, OPT_COMPRESS_LAYOUT, OPT_COMPRESS_WINDOW_MAX_BATCH,
- OPT_TABLE_PROBE_TRIES, OPT_TABLE_PROBE_MAX_BYTES, OPT_PARALLEL_DECODE_MIN, OPT_FENCED, OPT_DECODE_LEFTOVERS, OPT_CRC_TABLE_FREE) = range(1, 12)
+ OPT_TABLE_PROBE_TRIES, OPT_TABLE_PROBE_MAX_BYTES, OPT_PARALLEL_DECODE_MIN, OPT_FENCED, OPT_DECODE_LEFTOVERS, OPT_CRC_KERNEL) = range(1, 12)
 
 
 def declared_symbols() -> list[str]:

@@ -144,7 +144,7 @@ struct snp_ctx {
                              // a team of lanes per block, out of LDS); 0 = never.  Above 512 bytes the wave kernel is faster (768-1024 B:
                              // teams 180-260 GB/s, wave kernel 280-335; profiles/r02t_team_budget.jsonl).
     u32 small_min_blocks = 4096;   // ... in batches of at least this many blocks
-    int crc_kernel = 0;            // SNP_OPT_CRC_TABLE_FREE: 0 = three LDS tables of 11 + 11 + 10 bits (default), 1 = the table-free kernel (1.7 TB/s), 2 = four 8-bit tables (round 3)
+    int crc_kernel = 0;            // SNP_OPT_CRC_KERNEL: 0 = three LDS tables of 11 + 11 + 10 bits (default), 1 = the table-free kernel (1.7 TB/s), 2 = four 8-bit tables (round 3)
     int crc_bits() const { return crc_kernel == 1 ? 2 : crc_kernel == 2 ? 4 : 0; }
     bool no_prepass = false;       // SNP_OPT_DECODE_LAYOUT = 1: every block by the one-block-per-wavefront kernel
     bool small_lanes = false;      // SNAPPIER_HIP_SMALL=lanes: the block-per-lane kernel instead of a team of lanes per block
@@ -747,7 +747,7 @@ snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
             c->redo_grid = v == 1;
             c->redo_list = v == 2;
             return SNP_OK;
-        case SNP_OPT_CRC_TABLE_FREE:
+        case SNP_OPT_CRC_KERNEL:
             if (v < 0 || v > 2) return SNP_ERR_BAD_ARG;
             c->crc_kernel = static_cast<int>(v);
             return SNP_OK;
@@ -770,7 +770,7 @@ snp_status snp_ctx_get_option(const snp_ctx* c, int option, int64_t* out)
         case SNP_OPT_PARALLEL_DECODE_MIN: *out = c->par_min; return SNP_OK;
         case SNP_OPT_FENCED: *out = c->fenced & 1; return SNP_OK;
         case SNP_OPT_DECODE_LEFTOVERS: *out = c->redo_grid ? 1 : c->redo_list ? 2 : 0; return SNP_OK;
-        case SNP_OPT_CRC_TABLE_FREE: *out = c->crc_kernel; return SNP_OK;
+        case SNP_OPT_CRC_KERNEL: *out = c->crc_kernel; return SNP_OK;
         default: return SNP_ERR_BAD_ARG;
     }
 }

@@ -72,7 +72,7 @@ __device__ const CrcLut g_crc_lut{};
 // X8192 sliced 11 + 11 + 10: three lookups per accumulator instead of four (the kernel is bound by LDS instruction throughput: a 64-lane
 // ds_read_b32 is ~4.7 cycles of the CU's LDS pipeline with or without bank conflicts, profiles/r02n_microbench_lds_unaligned.jsonl), 20 KiB of LDS.
 struct CrcLut11 {
-    u32 t[5120];                                                        // [0, 2048): bits 0-10; [2048, 4096): bits 11-21; [4096, 5120): bits 22-31
+    alignas(16) u32 t[5120];                                            // [0, 2048): bits 0-10; [2048, 4096): bits 11-21; [4096, 5120): bits 22-31 (copied 16 bytes at a time)
     constexpr CrcLut11() : t{}
     {
         for (int k = 0; k < 3; ++k) {
@@ -98,7 +98,7 @@ __device__ __forceinline__ u32 xstep8(u32 v)
 constexpr u32 kCrcWaves = 4;   // byte ranges per workgroup (they share the LDS table)
 
 // MODE 1 (TABLE_FREE): the form BASELINE.json's north star names -- no table anywhere, X8192 applied bit by bit (32 x sbfe / and / xor
-// per dword: VALU-bound, 1.7 TB/s; SNP_OPT_CRC_TABLE_FREE selects it).  MODE 0: four 256-entry tables in LDS (4.5-5.3 TB/s).
+// per dword: VALU-bound, 1.7 TB/s; SNP_OPT_CRC_KERNEL selects it).  MODE 0: four 256-entry tables in LDS (4.5-5.3 TB/s).
 // MODE 2: three tables of 2048 / 2048 / 1024 entries (11 + 11 + 10 bits), three lookups per dword; a wavefront then takes kPer11 consecutive
 // byte ranges, so that the 20 KiB table is copied once per 16 ranges.
 #ifndef SNP_CRC_NT
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(SNP_WAVE * (MODE == 2 ? kWaves11 : kCrcWaves)) void
 {
     constexpr bool TABLE_FREE = MODE == 1;
     constexpr u32 kPer = MODE == 2 ? kPer11 : 1u, kWaves = MODE == 2 ? kWaves11 : kCrcWaves;
-    __shared__ u32 T[MODE == 2 ? 5120 : TABLE_FREE ? 1 : 1024];
+    __shared__ __attribute__((aligned(16))) u32 T[MODE == 2 ? 5120 : TABLE_FREE ? 1 : 1024];
     if constexpr (MODE == 0) {
         for (u32 e = threadIdx.x; e < 1024; e += SNP_WAVE * kWaves) T[e] = g_crc_lut.t[e >> 8][e & 255u];
         __syncthreads();
@@ -231,6 +231,9 @@ extern "C" hipError_t snp_launch_crc32c(const u8* in, const u64* in_off, const u
 {
     if (nblocks == 0) return hipSuccess;
     // masked: bit 0 = apply the framing mask, bit 1 = the table-free kernel, bit 2 = the 8-bit-sliced tables (round 3's default)
+    // (the three-table kernel amortises its 20 KiB table copy over kPer11 byte ranges per wavefront: a batch too small to fill the chip that way --
+    //  a few hundred frame chunks -- takes the 8-bit tables, one range per wavefront: ADVICE r4)
+    if (!(masked & 6) && nblocks < 16u * 256u * kWaves11) masked |= 4;
     const u32 waves = (masked & 6) ? kCrcWaves : kWaves11, per_wg = waves * ((masked & 6) ? 1u : kPer11);
     const dim3 grid((nblocks + per_wg - 1) / per_wg), block(SNP_WAVE * waves);
     if (masked & 2)

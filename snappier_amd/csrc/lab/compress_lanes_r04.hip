@@ -1,3 +1,7 @@
+// lab/compress_lanes_r04.hip -- the lane compressor as it stood in round 4, with its timing-only ablations and cache-policy experiments
+// (-DSNP_CL_ABLATE_RT=1, SNAPPIER_HIP_CL_ABLATE): NOT part of the product, links only into LAB=1 variant builds (scripts/build_variant.sh).
+// The product kernel is csrc/compress_lanes.hip: the same code without the experiment bits.
+//
 // compress_lanes.hip -- Snappy fragment compression, one <= 64 KiB fragment per LANE (gfx950), bit-exact with
 // SnappyCompressor.CompressFragment (Snappier/Internal/SnappyCompressor.cs:174-415) for both TableEntry hashes.
 //
@@ -15,7 +19,7 @@
 // instruction issue.  Batches below 16 384 fragments use compress_win.hip (one wavefront per fragment is better there).
 #include <cstdlib>
 
-#include "snp_device.h"
+#include "../snp_device.h"
 
 #ifndef SNP_CL_FLAT
 #define SNP_CL_FLAT 1     // 1: flat per-lane state machine (default); 0: the reference's nested loops, verbatim
@@ -47,6 +51,9 @@ __device__ __forceinline__ u32 check_bits(u32 bytes) { return (bytes * 0x9E3779B
 // stores (148.3 ms: the two halves of a read-modify-write want the sector to stay in L2 in between) and a 16-byte register window
 // over the input (one input load per ~9 probes: 121.2 ms alone, 112.4 with the exchange -- input requests hit L1 / L2 and are nearly
 // free at the table-rate bound); both were removed again.
+#ifndef SNP_CL_ABLATE_RT
+#define SNP_CL_ABLATE_RT 0   // 1: TIMING-ONLY ablations selectable per launch (SNAPPIER_HIP_CL_ABLATE, bits 8.. of the option word); scripts/ab_compress_ablate.py
+#endif
 __device__ __forceinline__ u32 table_swap(u32* p, u32 v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct LaneCtx {
@@ -183,6 +190,7 @@ constexpr u32 kStageStride = 100;      // bytes of LDS per lane: 96 usable (63 p
 struct OutStage {
     u8* lds;        // this lane's buffer
     u32 flushed;    // output bytes [0, flushed) are in global memory
+    bool mute;      // (SNP_CL_ABLATE_RT, ablation 4: the staged runs are not stored -- timing only)
 };
 
 __device__ __forceinline__ void stage_flush64(const LaneCtx& c, OutStage& st)
@@ -194,7 +202,7 @@ __device__ __forceinline__ void stage_flush64(const LaneCtx& c, OutStage& st)
     for (u32 i = 0; i < 64; i += 16) {
         const snp_u128_unaligned q = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + i);
         const v4u v = {q.v[0], q.v[1], q.v[2], q.v[3]};
-        __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(g + i));
+        if (!(SNP_CL_ABLATE_RT && st.mute)) __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(g + i));
     }
     const snp_u128_unaligned t0 = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + 64);
     const snp_u128_unaligned t1 = *reinterpret_cast<const snp_u128_unaligned*>(st.lds + 80);
@@ -221,23 +229,12 @@ __device__ __forceinline__ void stage_drain(const LaneCtx& c, OutStage& st, u32 
 // dynamic), the input, candidate and literal reads of a step are LDS reads and only the table accesses and the output stay on the
 // texture path.  Whether a batch qualifies is known only on the device (max_len), so the host launches this kernel in front of the
 // general one whenever the previous batch was small, and each of the two returns at once if the batch is not its own.
-// Launch options of k_compress_lanes (`opts`, chosen per launch from the batch size by snp_launch_compress_lanes; results never depend on them):
-enum : int {
-    kOptBlindLiterals = 1,    // short literals leave as one 16-byte store (inside MaxCompressedLength)
-    kOptBlindLiteral16 = 2,   // ... also the 16-byte form of lane_emit_literal16
-    kOptBlindCopies = 4,      // copy tags as one 4-byte store
-    kOptShortExtend = 8,      // match extension: 16 + 16 bytes per trip only
-    kOptStagedOutput = 16,    // output staged per lane in LDS, leaving in 64-byte non-temporal runs (launches of >= 32 768 fragments)
-    kOptExchangeProbe = 64,   // probe + insert as ONE atomic exchange (one probe per trip only)
-    kOptInputWindow = 128,    // the probe bytes out of a 16-byte register window over the input (launches of >= 131 072 fragments)
-};
-
 template <int VARIANT, u32 kSlots, bool SMALL>
 __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restrict__ in, const u64* __restrict__ in_off,
                                                             const u32* __restrict__ in_len, u32 nblocks,
                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
                                                             u32* __restrict__ out_len, i32* __restrict__ status,
-                                                            int emit_varint, const snp_table_pieces tp, int opts,
+                                                            int emit_varint, const snp_table_pieces tp, int lit_blind,
                                                             const u32* __restrict__ max_len, u32 small_max)
 {
     __shared__ u16 lut[4][256];
@@ -277,10 +274,10 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // other lanes' stores, before this lane probes its table
     }
     if (b >= nblocks) return;
-    const bool staged = (opts & kOptStagedOutput) != 0;
-    const bool t_swap = kSlots == 1 && (opts & kOptExchangeProbe) != 0;          // probe + insert as one atomic exchange (one probe per trip only)
-    bool in_win = (opts & kOptInputWindow) != 0;                              // 16-byte register window over the input for the probe bytes (n >= 32, set below)
-    OutStage stg{(SMALL ? s_dyn + blockDim.x * (small_max + 16u) : s_out) + threadIdx.x * kStageStride, 0};
+    const bool staged = (lit_blind & 16) != 0;
+    const bool t_swap = kSlots == 1 && (lit_blind & 64) != 0;          // probe + insert as one atomic exchange (one probe per trip only)
+    bool in_win = (lit_blind & 128) != 0;                              // 16-byte register window over the input for the probe bytes (n >= 32, set below)
+    OutStage stg{(SMALL ? s_dyn + blockDim.x * (small_max + 16u) : s_out) + threadIdx.x * kStageStride, 0, SNP_CL_ABLATE_RT && (lit_blind & 0x400) != 0};
 
     LaneCtx c;
     c.dst = out + out_off[b];
@@ -341,7 +338,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
     //           from registers and a match shorter than 16 finished without another trip.
     // (The first version waited for each of these in turn plus a load per literal piece and four extension steps:
     // ~10 trips per loop trip, and the loop trip is what 64 lanes pay together.)
-    const u32 lit_cap = (opts & kOptBlindLiterals) ? 32u + n + n / 6u : 0u;            // blind 16-byte literal stores stay inside MaxCompressedLength
+    const u32 lit_cap = (lit_blind & 1) ? 32u + n + n / 6u : 0u;            // blind 16-byte literal stores stay inside MaxCompressedLength
     while (__any(mode != kDone)) {
         u32 cp_len = 0, cp_off = 0;                                     // the copy this trip ends with, emitted once below
         u32 lit_len = 0;                                                // the literal this trip ends with (staged mode: emitted below)
@@ -373,6 +370,10 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 if (o > 8u) {
                     win_at = min(at, n - 16u);                          // at <= limit = n - 15: the window is pulled back inside the fragment
                     win = *reinterpret_cast<const snp_u128_unaligned*>(c.src + win_at);
+                    if (SNP_CL_ABLATE_RT && (lit_blind & 0x800)) {              // (ablation 8: the window load once more, the 16 bytes before it)
+                        const snp_u128_unaligned e = *reinterpret_cast<const snp_u128_unaligned*>(c.src + (win_at >= 16 ? win_at - 16 : win_at));
+                        asm volatile("" ::"v"(e.v[0] ^ e.v[3]));
+                    }
                     o = at - win_at;                                    // 0 or 1
                 }
                 const u32 dq = o >> 2, sh = (o & 3u) * 8u;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
             const u8* bq = c.src + base + mlen;
             xa0 = *reinterpret_cast<const snp_u128_unaligned*>(a);
             xb0 = *reinterpret_cast<const snp_u128_unaligned*>(bq);
-            if (!(opts & kOptShortExtend)) {
+            if (!(lit_blind & 8)) {                                     // option bit 3: only 16 + 16 bytes per trip
                 xa1 = *reinterpret_cast<const snp_u128_unaligned*>(a + 16);
                 xb1 = *reinterpret_cast<const snp_u128_unaligned*>(bq + 16);
             }
@@ -410,11 +411,15 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 const u32 dm1 = static_cast<u32>(w0);
                 hm1 = lane_hash<VARIANT>(c, dm1, lut);
                 vm1 = (ip - 1) | check_bits(dm1);
-                // full-size tables: non-temporal -- nothing reads the entry soon, and the probe that one day does is an atomic that goes to
-                // L2 / memory anyway (same-workspace interleaved A/B 96.46 -> 96.13 ms, profiles/r04g_compress_insert_store_kinds.json;
-                // an agent-scope (sc1) store: 96.41).  Small tables live in L2 and keep the plain store.
-                if (tstride == 16384u) __builtin_nontemporal_store(vm1, &c.table[hm1]);
-                else c.table[hm1] = vm1;
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x4000)) __builtin_nontemporal_store(vm1, &c.table[hm1]);             // (experiment 64: non-temporal)
+                else if (SNP_CL_ABLATE_RT && (lit_blind & 0x8000)) __hip_atomic_store(&c.table[hm1], vm1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (experiment 128: sc1)
+                else if (!(SNP_CL_ABLATE_RT && (lit_blind & 0x100))) {                      // (ablation 1: the ip - 1 insert is not stored)
+                    // full-size tables: non-temporal -- nothing reads the entry soon, and the probe that one day does is an atomic that goes to
+                    // L2 / memory anyway (same-workspace interleaved A/B 96.46 -> 96.13 ms, profiles/r04g_compress_insert_store_kinds.json;
+                    // an agent-scope (sc1) store: 96.41).  Small tables live in L2 and keep the plain store.
+                    if (tstride == 16384u) __builtin_nontemporal_store(vm1, &c.table[hm1]);
+                    else c.table[hm1] = vm1;
+                }
                 d[0] = static_cast<u32>(w0 >> 8);
             } else {
                 d[0] = static_cast<u32>(w0);
@@ -433,7 +438,29 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 // one probe per trip and it is always inserted when legal (:333 / :397), so read + insert is one exchange; a probe into
                 // the bucket the ip - 1 insert of this same trip just wrote takes that entry from the register instead
                 swapped = legal[0] && h[0] != hm1;
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x1c0000)) {     // (experiments 1024 / 2048 / 4096: the exchange through inline asm with cache-policy bits: sc0 | sc0 nt | sc0 sc1)
+                    const u32 nv = p[0] | check_bits(d[0]);
+                    u32 old = vm1;
+                    if (legal[0] && swapped) {
+                        u32* const ap = &c.table[h[0]];
+                        if (lit_blind & 0x40000) asm volatile("global_atomic_swap %0, %1, %2, off sc0\n s_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ap), "v"(nv) : "memory");
+                        else if (lit_blind & 0x80000) asm volatile("global_atomic_swap %0, %1, %2, off sc0 nt\n s_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ap), "v"(nv) : "memory");
+                        else asm volatile("global_atomic_swap %0, %1, %2, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ap), "v"(nv) : "memory");
+                    }
+                    cv[0] = !legal[0] ? 0u : old;
+                } else
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x30000)) {      // (experiments 256 / 512: the exchange at workgroup / wavefront scope -- the table is lane-private, any scope is correct)
+                    const u32 nv = p[0] | check_bits(d[0]);
+                    cv[0] = !legal[0] ? 0u : !swapped ? vm1
+                            : (lit_blind & 0x10000) ? __hip_atomic_exchange(&c.table[h[0]], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                                    : __hip_atomic_exchange(&c.table[h[0]], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                } else
                 cv[0] = !legal[0] ? 0u : swapped ? table_swap(&c.table[h[0]], p[0] | check_bits(d[0])) : vm1;
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x2000) && swapped) {   // (ablation 32: one more exchange + store per probe, elsewhere in this lane's table, net effect none)
+                    u32* const other = &c.table[h[0] ^ 0x2000u];
+                    const u32 keep = table_swap(other, 0u);
+                    *other = keep;
+                }
             } else {
 #pragma unroll
                 for (u32 k = 0; k < kSlots; ++k) cv[k] = legal[k] ? c.table[h[k]] : 0u;   // :329 / :396  (position | check bits)
@@ -450,7 +477,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 finished = true;
                 if (x0) mlen += static_cast<u32>(__builtin_ctzll(x0)) >> 3;
                 else if (x1) mlen += 8 + (static_cast<u32>(__builtin_ctzll(x1)) >> 3);
-                else if (opts & kOptShortExtend) { mlen += 16; finished = false; }
+                else if (lit_blind & 8) { mlen += 16; finished = false; }
                 else if (x2) mlen += 16 + (static_cast<u32>(__builtin_ctzll(x2)) >> 3);
                 else if (x3) mlen += 24 + (static_cast<u32>(__builtin_ctzll(x3)) >> 3);
                 else { mlen += 32; finished = false; }
@@ -497,6 +524,13 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                 cb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + wpos);
                 pb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + wp);
                 if (!post) lb = *reinterpret_cast<const snp_u128_unaligned*>(c.src + next_emit);
+                if (SNP_CL_ABLATE_RT && (lit_blind & 0x200)) {          // (ablation 2: the three loads once more, 64 bytes further back / on)
+                    const snp_u128_unaligned e0 = *reinterpret_cast<const snp_u128_unaligned*>(c.src + (wpos >= 64 ? wpos - 64 : wpos));
+                    const snp_u128_unaligned e1 = *reinterpret_cast<const snp_u128_unaligned*>(c.src + (wp >= 64 ? wp - 64 : wp));
+                    snp_u128_unaligned e2 = e0;
+                    if (!post) e2 = *reinterpret_cast<const snp_u128_unaligned*>(c.src + (next_emit >= 64 ? next_emit - 64 : next_emit));
+                    asm volatile("" ::"v"(e0.v[0] ^ e1.v[1] ^ e2.v[2]));
+                }
             }
             // in-order resolution: probes before kw missed, kw is decided by the bytes, probes after it did not happen
             bool ended = false;
@@ -519,7 +553,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
                     if (hit) {
                         if (!post) {                                    // :347
                             if (staged) { lit_len = wp - next_emit; lit16 = lb; }
-                            else op = lane_emit_literal16(c, op, next_emit, wp - next_emit, lb, lit_cap, (opts & kOptBlindLiteral16) != 0);
+                            else op = lane_emit_literal16(c, op, next_emit, wp - next_emit, lb, lit_cap, (lit_blind & 2) != 0);
                         }
                         base = wp;
                         cand = wpos;
@@ -552,7 +586,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
             }
         }
         if (!staged) {
-            if (cp_len) op = lane_emit_copy(c.dst, op, cp_off, cp_len, (opts & kOptBlindCopies) ? lit_cap : 0u);   // after this trip's literal, if any
+            if (cp_len) op = lane_emit_copy(c.dst, op, cp_off, cp_len, (lit_blind & 4) ? lit_cap : 0u);   // after this trip's literal, if any
         } else {
             // literal (next_emit is still the literal's start: it only changes when a scan begins), then the copy
             if (lit_len) {
@@ -734,7 +768,8 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const char* ex = SNP_GETENV("SNAPPIER_HIP_EXACT_LITERALS");
     const char* oe = SNP_GETENV("SNAPPIER_HIP_CL_OPTS");
     // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
-    const int opts = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0)));   // (kOptExchangeProbe acts in one-probe-per-trip launches only)
+    const char* ab = SNP_GETENV("SNAPPIER_HIP_CL_ABLATE");              // (acts in -DSNP_CL_ABLATE_RT=1 builds only: timing-only ablations, bits 8.. of the option word)
+    const int lit_blind = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0))) | ((SNP_CL_ABLATE_RT && ab) ? (atoi(ab) & 8191) << 8 : 0);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = SNP_GETENV("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
@@ -766,7 +801,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
             break;                                                                                                                                  \
         }                                                                                                                                           \
         hipLaunchKernelGGL((k_compress_lanes<V, 2, true>), dim3(sgrid), dim3(sper), dyn, stream, in, in_off, in_len, nblocks, out, out_off, out_len, status, \
-                           emit_varint, *tables, opts, max_len, small_max);                                                                    \
+                           emit_varint, *tables, lit_blind, max_len, small_max);                                                                    \
         small_ok = hipGetLastError() == hipSuccess;                                                                                                 \
     } while (0)
         if (variant == SNP_HASH_CRC32C) SNP_LAUNCH_SMALL(SNP_HASH_CRC32C); else SNP_LAUNCH_SMALL(SNP_HASH_MUL);
@@ -778,7 +813,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     }
 #define SNP_LAUNCH_CL(V, S)                                                                                          \
     hipLaunchKernelGGL((k_compress_lanes<V, S, false>), dim3(grid), dim3(per), 0, stream, in, in_off, in_len, nblocks, out,    \
-                       out_off, out_len, status, emit_varint, *tables, opts, max_len, small_max)
+                       out_off, out_len, status, emit_varint, *tables, lit_blind, max_len, small_max)
     if (variant == SNP_HASH_CRC32C) { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 1); else if (slots >= 4) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 4); else if (slots == 3) SNP_LAUNCH_CL(SNP_HASH_CRC32C, 3); else SNP_LAUNCH_CL(SNP_HASH_CRC32C, 2); }
     else { if (slots == 1) SNP_LAUNCH_CL(SNP_HASH_MUL, 1); else if (slots >= 4) SNP_LAUNCH_CL(SNP_HASH_MUL, 4); else if (slots == 3) SNP_LAUNCH_CL(SNP_HASH_MUL, 3); else SNP_LAUNCH_CL(SNP_HASH_MUL, 2); }
 #undef SNP_LAUNCH_CL

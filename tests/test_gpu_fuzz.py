@@ -343,7 +343,7 @@ def test_context_options_pin_layouts_without_changing_results():
 
 
 def test_crc32c_table_free_kernel_equals_the_table_kernel_and_the_oracle():
-    """SNP_OPT_CRC_TABLE_FREE = 1 (the kernel BASELINE.json's north star names: no table, the GF(2) shift map bit by bit), 0 (the default: three
+    """SNP_OPT_CRC_KERNEL = 1 (the kernel BASELINE.json's north star names: no table, the GF(2) shift map bit by bit), 0 (the default: three
     LDS tables of 11 + 11 + 10 bits, four byte ranges per wavefront -- so the ragged list also ends inside a wavefront's group of four) and 2 (round 3's
     four 8-bit tables) against the oracle (Crc32CAlgorithm.cs:41-158): ragged lengths 0 .. 70 000, masked and unmasked, and through the
     framing format (snp_frame_encode computes every chunk's CRC with the selected kernel, snp_frame_decode verifies with it)."""
@@ -355,15 +355,15 @@ def test_crc32c_table_free_kernel_equals_the_table_kernel_and_the_oracle():
     data, off, ln = batch_of(blocks)
     want = {m: np.array([O.crc32c(b.tobytes(), masked=m) for b in blocks], dtype=np.uint32) for m in (False, True)}
     for table_free in (1, 0, 2, 1):
-        cd.ctx.set_option(N.OPT_CRC_TABLE_FREE, table_free)
-        assert cd.ctx.get_option(N.OPT_CRC_TABLE_FREE) == table_free
+        cd.ctx.set_option(N.OPT_CRC_KERNEL, table_free)
+        assert cd.ctx.get_option(N.OPT_CRC_KERNEL) == table_free
         for m in (False, True):
             got = cd.crc32c(dev(data), dev(off), dev(ln), masked=m).cpu().numpy().astype(np.uint32)
             assert np.array_equal(got, want[m]), (table_free, m, np.nonzero(got != want[m])[0][:5])
         payload = read_testdata("html") * 2
         framed = S.frame_encode(payload, cd.ctx)
         assert framed == O.frame_encode(payload) and S.frame_decode(framed, cd.ctx) == payload
-    cd.ctx.set_option(N.OPT_CRC_TABLE_FREE, 0)
+    cd.ctx.set_option(N.OPT_CRC_KERNEL, 0)
 
 
 def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
