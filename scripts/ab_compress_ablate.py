@@ -9,6 +9,8 @@ SNAPPIER_HIP_LIB=...; SNAPPIER_HIP_CL_ABLATE is read per launch).  What owns the
       random exchanges + 1.63 G more random stores
   64 / 128  the ip - 1 insert as a non-temporal / an agent-scope (sc1) store -- experiments, results unchanged
   256 / 512  the probe exchange at workgroup / wavefront scope instead of agent scope (the table is lane-private) -- experiments, results unchanged
+  8192  (round 5) the tables are zeroed TWICE at the head of the kernel: time(8192) - time(0) = what zeroing costs, the most an epoch tag in
+        the entries could save (results unchanged)
   1024 / 2048 / 4096  the exchange through inline asm (waited for at once) with sc0 | sc0 nt | sc0 sc1 -- compare these three with each other
 Masks 0, 2, 8, 32, 64, 128, 256, 512, 1024, 2048, 4096 must produce the reference bytes (checked); 1 and 4 are wrong by construction.
    python scripts/ab_compress_ablate.py [masks...]   DATA=html|mixed   ->  one JSON line"""
@@ -48,7 +50,7 @@ for rep in range(int(os.environ.get("REPS", "4"))):
         res[m].append(round(ms, 2))
         tot = int(out_len.to(torch.int64).sum().item())
         total[m] = tot
-        if m in (0, 2, 8, 32, 10, 34, 40, 42, 64, 128, 256, 512, 1024, 2048, 4096):
+        if m in (0, 2, 8, 32, 10, 34, 40, 42, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
             crcs = cd.crc32c(comp, comp_off, out_len)
             sig = (tot, int(crcs.to(torch.int64).sum().item()))
             ref = sig if ref is None else ref

@@ -267,6 +267,11 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_lanes(const u8* __restric
             const v4u zero4 = {0, 0, 0, 0};
             for (size_t i = static_cast<size_t>(threadIdx.x) * 4; i < words; i += static_cast<size_t>(blockDim.x) * 4)
                 __builtin_nontemporal_store(zero4, reinterpret_cast<v4u*>(wt + i));
+            if (SNP_CL_ABLATE_RT && (lit_blind & 0x200000)) {           // (ablation 8192, round 5: the tables are zeroed TWICE -- time(8192) - time(0) = what zeroing costs,
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        //  the most an epoch tag in the entries could save; results unchanged)
+                for (size_t i = static_cast<size_t>(threadIdx.x) * 4; i < words; i += static_cast<size_t>(blockDim.x) * 4)
+                    __builtin_nontemporal_store(zero4, reinterpret_cast<v4u*>(wt + i));
+            }
         } else {
             for (size_t i = static_cast<size_t>(threadIdx.x) * 4; i < words; i += static_cast<size_t>(blockDim.x) * 4)
                 *reinterpret_cast<uint4*>(wt + i) = make_uint4(0, 0, 0, 0);
@@ -769,7 +774,7 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const char* oe = SNP_GETENV("SNAPPIER_HIP_CL_OPTS");
     // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
     const char* ab = SNP_GETENV("SNAPPIER_HIP_CL_ABLATE");              // (acts in -DSNP_CL_ABLATE_RT=1 builds only: timing-only ablations, bits 8.. of the option word)
-    const int lit_blind = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0))) | ((SNP_CL_ABLATE_RT && ab) ? (atoi(ab) & 8191) << 8 : 0);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
+    const int lit_blind = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0))) | ((SNP_CL_ABLATE_RT && ab) ? (atoi(ab) & 16383) << 8 : 0);   // bit 6 (atomic-exchange probes) acts in one-probe-per-trip launches only
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = SNP_GETENV("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
