@@ -73,7 +73,7 @@ public sealed class GpuContext : SafeHandle
         return v;
     }
 
-    /// <summary>snp_ctx_reserve_compress: builds the compressor's hash-table workspace for batches of up to <paramref name="fragments"/>
+    /// <summary>snp_ctx_reserve_compress: builds the DEVICE's hash-table workspace (shared by every context on it) for batches of up to <paramref name="fragments"/>
     /// 64 KiB fragments now -- call once at service start-up, before other allocations crowd the device, so that the first large
     /// request does not pay for the placement search.</summary>
     public void ReserveCompress(uint fragments) => Snappy.ThrowIfFailed(NativeMethods.snp_ctx_reserve_compress(handle, fragments));

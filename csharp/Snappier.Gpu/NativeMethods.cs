@@ -30,8 +30,8 @@ public enum SnpOption : int
     SmallBlockMinBatch = 3,
     CompressLayout = 4,         // 0 by batch size, 2 fragment per lane (HBM tables), 3 fragment per wavefront (LDS table)
     CompressWindowMaxBatch = 5,
-    TableProbeTries = 6,
-    TableProbeMaxBytes = 7,     // cap on the transient footprint of the hash-table placement probe
+    TableProbeTries = 6,        // workspaces' worth of candidate pieces the DEVICE's hash-table workspace search may hold (default 2; 3..24 = the thorough search, 1 = a plain workspace of the context's own)
+    TableProbeMaxBytes = 7,     // cap on the transient footprint of that search (default: half of free memory; an explicit cap is honoured up to 7/8)
     ParallelDecodeMin = 8,
     Fenced = 9,
     DecodeLeftovers = 10,
