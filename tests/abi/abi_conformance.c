@@ -82,6 +82,26 @@ static void* worker(void* p)
     return NULL;
 }
 
+/* ---- a device LIST behind one caller (csharp/Snappier.Gpu/MultiDeviceChunkCodec.cs, snappier_amd/multidevice.py): the run of chunks is cut into
+ * contiguous whole-chunk ranges, each range is framed by its own context on its own thread, the host concatenates (stream identifier once). */
+typedef struct {
+    fn_ctx_create ctx_create; fn_ctx_destroy ctx_destroy; fn_buf frame_encode; fn_len frame_max;
+    int device; const uint8_t* piece; size_t n; uint8_t* out; size_t written; int ok;
+} range_arg;
+
+static void* range_worker(void* p)
+{
+    range_arg* a = (range_arg*)p;
+    void* ctx = NULL;
+    a->ok = 0;
+    if (a->ctx_create(a->device, SNP_HASH_CRC32C, NULL, &ctx) != SNP_OK || !ctx) return NULL;
+    const size_t cap = (size_t)a->frame_max((int64_t)a->n);
+    a->out = malloc(cap);
+    a->ok = a->frame_encode(ctx, a->piece, a->n, a->out, cap, &a->written) == SNP_OK;
+    a->ctx_destroy(ctx);
+    return NULL;
+}
+
 static void* must(void* lib, const char* name)
 {
     void* p = dlsym(lib, name);
@@ -287,6 +307,43 @@ int main(int argc, char** argv)
             EXPECT(args[t].created == 1 && args[t].fails == 0);
         }
         printf("%d threads x 6 round trips on %d device(s): %s\n", kThreads, ndev, g_fail ? "FAIL" : "ok");
+    }
+    /* ---- the device-list sequence: devices = {0, 0, ... one entry per device, at least two}: ranges framed on separate contexts and threads,
+     * concatenated on the host, must be the bytes ONE context produces for the whole run, and decode back through one context ------------ */
+    {
+        enum { kRanges = 3 };
+        const size_t chunks = (n + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
+        size_t wl = 0;
+        EXPECT(frame_encode(ctx, data, n, framed, fcap, &wl) == SNP_OK);                /* the single-context bytes */
+        pthread_t th[kRanges];
+        range_arg args[kRanges];
+        size_t first = 0;
+        int used = 0;
+        for (int r = 0; r < kRanges && first < chunks; ++r, ++used) {
+            size_t cnt = chunks / kRanges + ((size_t)r < chunks % kRanges ? 1 : 0);
+            if (cnt == 0) cnt = 1;
+            if (first + cnt > chunks || r == kRanges - 1) cnt = chunks - first;
+            const size_t lo = first * SNP_BLOCK_SIZE, hi = (first + cnt) * SNP_BLOCK_SIZE < n ? (first + cnt) * SNP_BLOCK_SIZE : n;
+            args[r] = (range_arg){ctx_create, ctx_destroy, frame_encode, frame_max, 0, data + lo, hi - lo, NULL, 0, 0};
+            EXPECT(pthread_create(&th[r], NULL, range_worker, &args[r]) == 0);
+            first += cnt;
+        }
+        uint8_t* joined = malloc(fcap + 64);
+        size_t at = 0;
+        for (int r = 0; r < used; ++r) {
+            pthread_join(th[r], NULL);
+            EXPECT(args[r].ok);
+            if (!args[r].ok) continue;
+            const size_t skip = r ? SNP_STREAM_HEADER_LEN : 0;                             /* the identifier is written once */
+            memcpy(joined + at, args[r].out + skip, args[r].written - skip);
+            at += args[r].written - skip;
+            free(args[r].out);
+        }
+        EXPECT(at == wl && memcmp(joined, framed, wl) == 0);
+        size_t w2 = 0;
+        EXPECT(frame_decode(ctx, joined, at, back, n, &w2) == SNP_OK && w2 == n && memcmp(back, data, n) == 0);
+        printf("device list: %d ranges of whole chunks on their own contexts, concatenated: %s\n", used, g_fail ? "FAIL" : "same bytes as one context");
+        free(joined);
     }
     ctx_destroy(ctx);
     free(comp); free(back); free(exact); free(framed);

@@ -42,3 +42,4 @@ def test_abi_conformance_device_part():
     assert torch.cuda.is_available()
     r = subprocess.run([build(), LIB, "device", os.path.join(TESTDATA, "lcet10.txt")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "conforming (device part)" in r.stdout and "FAIL" not in r.stdout, r.stdout + r.stderr
+    assert "same bytes as one context" in r.stdout, r.stdout        # the device-list sequence (MultiDeviceChunkCodec) ran
