@@ -16,7 +16,10 @@ for n in names:
     row = {"file": n, "blocks": nb}
     comp = None
     for m in modes:
-        os.environ["SNAPPIER_HIP_DECODE"] = m
+        if m == "default":                  # the library's own default, no knob set (the product library when SNAPPIER_HIP_LIB is not set either)
+            os.environ.pop("SNAPPIER_HIP_DECODE", None)
+        else:
+            os.environ["SNAPPIER_HIP_DECODE"] = m
         cd = SB.BlockCodec(0, S.HASH_CRC32C)
         in_off, in_len = cd.uniform_layout(nb)
         if comp is None:

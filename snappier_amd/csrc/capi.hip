@@ -124,6 +124,15 @@ TablePool* pool_of(int device)
 
 }  // namespace
 
+// Scope in which this thread's potentially capture-unsafe calls (event / stream queries, a synchronous read-back) are legal although another
+// thread may be capturing in global mode.
+struct RelaxedCaptureMode {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    bool ok;
+    RelaxedCaptureMode() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; if (!ok) (void)hipGetLastError(); }
+    ~RelaxedCaptureMode() { if (ok && hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
+};
+
 struct snp_ctx {
     int device = 0;
     int variant = SNP_HASH_CRC32C;
@@ -183,6 +192,9 @@ struct snp_ctx {
             // (a stream that is being captured into a graph is never queried or synchronised, and no event of this context is: all of that would
             //  invalidate the capture.  A captured call goes by what the context knew before the capture began and leaves no hint behind.)
             const bool capturing = stream_is_capturing();
+            // (the queries and the one-time synchronous sample below touch only this context's stream and events; in relaxed mode they do not
+            //  invalidate a hipStreamCaptureModeGlobal capture that ANOTHER thread of the process has in progress: ADVICE r4)
+            RelaxedCaptureMode relaxed;
             if (capturing) {
             } else if (hint && hint_ev && hint_pending && hipEventQuery(hint_ev) == hipSuccess) {
                 hint_pending = false;
