@@ -90,3 +90,13 @@ def default_context(hash_variant: int | None = None) -> Context:
     if key not in cache:
         cache[key] = Context(0, key[0])
     return cache[key]
+
+
+def close_default_contexts() -> None:
+    """Closes this thread's cached default contexts (a device's table pool lives as long as its last context: tests of the pool's lifetime
+    call this first, so that the order they run in does not matter)."""
+    cache = getattr(_tls, "ctx", None)
+    if cache:
+        for c in cache.values():
+            c.close()
+        cache.clear()

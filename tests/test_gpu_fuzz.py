@@ -375,6 +375,8 @@ def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
     N = S._native
     import gc
     from snappier_amd import datagen as SD
+    from snappier_amd import context as SC
+    SC.close_default_contexts()
     gc.collect()                                                       # (contexts of earlier tests: the device's pool dies with the last of them)
     html = read_testdata("html")
     sizes = (20001, 36000)                                             # 1.3 GB and 2.4 GB of tables: 16 pieces of 1344 / 2432 fragments

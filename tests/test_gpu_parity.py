@@ -45,7 +45,10 @@ def assert_same(tag, got: bytes, ref: bytes):
 
 @pytest.fixture(scope="module")
 def codec():
-    return {v: SB.BlockCodec(0, v) for v in VARIANTS}
+    cds = {v: SB.BlockCodec(0, v) for v in VARIANTS}
+    yield cds
+    for cd in cds.values():                 # (a device's table pool lives as long as its last context: later modules test its lifetime)
+        cd.ctx.close()
 
 
 def to_dev(a: np.ndarray):
