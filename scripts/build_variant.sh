@@ -7,6 +7,9 @@
 #                                                          SNAPPIER_HIP_* knobs act: the product library reads no environment)
 #     LAB=1 CLAB=1 SRC=compress_lanes.hip scripts/build_variant.sh clablate -DSNP_CL_ABLATE_RT=1
 #                                                          ... with lab/compress_lanes_r04.hip (the lane compressor with its timing-only ablations)
+#     PATCH=scripts/lab_patches/decode_chains_prof_abl.patch scripts/build_variant.sh prof -DSNP_DC_PROF=1
+#                                                          the varied source is a patched COPY (/tmp): instrumentation that never enters the product
+#                                                          source (per-phase shader-clock budget: scripts/r5_decode_prof.py; -DSNP_DC_ABL=mask: timing-only removals)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
@@ -32,7 +35,14 @@ for f in $FILES; do
     fi
   fi
 done
-/opt/rocm/bin/hipcc $FLAGS "$@" -c snappier_amd/csrc/$SRC -o $OBJ/variant_$name.o
+VSRC=snappier_amd/csrc/$SRC
+if [ -n "${PATCH:-}" ]; then
+  VSRC=$OBJ/patched_${name}_$(basename $SRC)
+  cp snappier_amd/csrc/$SRC $VSRC
+  patch -s $VSRC < $PATCH
+  FLAGS="$FLAGS -Isnappier_amd/csrc"
+fi
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $VSRC -o $OBJ/variant_$name.o
 objs=""
 for f in $FILES; do
   if [ "$f.hip" == "$SRC" ]; then objs="$objs $OBJ/variant_$name.o"; else objs="$objs $OBJ/$(basename $f).o"; fi
