@@ -40,9 +40,11 @@ for i in range(3):
 L.snp_debug_decode_prof(prof, 0)
 ok = bool(torch.equal(back, raw))
 names = {0: "glue (loop top, exits)", 1: "S stage the window, advance table", 2: "A walk", 3: "A' overrun walk", 4: "R reach / resolve", 5: "T tag list",
-         6: "batch top (tag bytes, decode, prefix sum, checks)", 14: "pass 1: ready masks, fence (vmcnt(0) on the previous write-out), tag-byte prefetch issue", 13: "pass 1: loads issued to data back (vmcnt(0))", 7: "pass 1: stage stores",
-         8: "finish (in order)", 9: "write-out", 10: "long literal by the whole wave"}
+         6: "batch top (tag bytes, decode, prefix sum, checks)", 14: "new batch: classes, fence, tag-byte prefetch, far / literal loads ISSUED",
+         8: "held batch: finish (in order)", 13: "new batch: loads waited for (vmcnt(0))", 9: "held batch: write-out",
+         7: "new batch: near copies from the stage, history, stage stores, hold", 10: "drain before a window build / exit (finish + write-out)"}
+order = (0, 1, 2, 3, 4, 5, 6, 14, 8, 13, 9, 7, 10)
 tot = sum(prof[i] for i in names)
-rows = [{"phase": names[i], "cycles_per_block": round(prof[i] / nb), "share": round(prof[i] / tot, 4)} for i in (0, 1, 2, 3, 4, 5, 6, 14, 13, 7, 8, 9, 10)]
+rows = [{"phase": names[i], "cycles_per_block": round(prof[i] / nb), "share": round(prof[i] / tot, 4)} for i in order]
 print(json.dumps({"data": kind, "blocks": nb, "ms": [round(m, 2) for m in ms], "roundtrip_ok": ok, "batches_per_block": round(prof[11] / nb, 1),
-                  "windows_per_block": round(prof[12] / nb, 2), "cycles_per_block": round(tot / nb), "cycles_per_batch": round(tot / max(prof[11], 1)), "phases": rows}))
+                  "windows_per_block": round(prof[12] / nb, 2), "drains_per_block": round(prof[15] / nb, 2), "cycles_per_block": round(tot / nb), "cycles_per_batch": round(tot / max(prof[11], 1)), "phases": rows}))

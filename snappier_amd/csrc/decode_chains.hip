@@ -3,7 +3,7 @@
 // Replaces the tag loop of SnappyDecompressor.DecompressAllTags + Append / AppendFromSelf
 // (Snappier/Internal/SnappyDecompressor.cs:184-347,568-611; copy semantics CopyHelpers.cs:222-230) for whole blocks.
 //
-// The kernel is bound by instruction issue, so everything here is shaped by instruction count, not by bytes moved.
+// The kernel is bound by a wavefront's own chain of latencies: what shapes the code is which waits sit on that chain.
 //
 //   PARSE, one SUPER-WINDOW of 64 x 32 = 2 KiB of compressed input at a time.  Where do the tags start?  Every lane walks a chain of tags
 //   through its own 32-byte region, starting blindly at the region's first byte.  A chain that starts inside a tag reads garbage, but a
@@ -19,14 +19,20 @@
 //     T   true tag starts = each such lane's V_k from its entry on, plus its overrun positions: a 2048-bit map whose popcount prefix
 //         numbers the tags; the positions are written out as a u16 list (over the table).
 //
-//   EXECUTE, 64 tags at a time, one per lane: tag bytes (one 8-byte load per lane, requested a batch ahead) -> decode -> DPP prefix sum
-//   of the output lengths -> the batch's bytes are assembled in a 2 KiB LDS stage and leave as one coalesced write:
-//     pass 1  literals and copies whose source lies below the batch: 16-byte pieces from global memory into the stage;
-//     pass 2  copies whose source lies inside the batch and is not the output of a tag that is still pending (a bitmap of pending
-//             output bytes decides), lane-parallel, stage to stage;
-//     finish  what is left (dependency chains inside the batch, pattern copies), in order, whole wave per tag, a byte per lane.
-//   A batch ends before the first tag it cannot take (malformed, a literal > 64 bytes, the last 16 output bytes): a long literal is
-//   copied by the whole wave and parsing goes on; anything else falls to serial_tail(), which owns the reference's error semantics.
+//   EXECUTE, 64 tags at a time, one per lane, TWO BATCHES IN FLIGHT.  A batch's bytes are assembled in a 2 KiB LDS stage (+ 64 bytes of
+//   history below it) and leave as one coalesced write; the batch in the stage is HELD while the next one starts:
+//     top     the new batch: tag bytes (a 4-byte gather requested a batch ahead) -> decode -> DPP prefix sum of the output lengths -> where
+//             does each tag's source lie?  literals and FAR copies (source ends at or below the held batch's first byte: global memory):
+//             their 16-byte pieces are requested now;
+//     finish  the HELD batch's waiting tags (source inside their own batch, pattern copies), in order, whole wave per tag, a byte per
+//             lane -- the new batch's round trip to memory runs underneath;
+//     write   the new batch's pieces are waited for (they are back), then the held batch leaves: stage -> global memory, 16 bytes per lane;
+//     stage   NEAR copies of the new batch (source inside the held batch or the history) read their pieces from the stage; the last 64
+//             bytes of what the stage holds move below its first byte (the new batch's history); every piece is stored; the new batch
+//             is now the held one.
+//   Nothing is held across a super-window build (it uses the stage as scratch), a literal > 64 bytes (copied by the whole wave) or an exit.
+//   A batch ends before the first tag it cannot take (malformed, a literal > 64 bytes, the last 16 output bytes); anything irregular falls
+//   to serial_tail(), which owns the reference's error semantics.
 #include "decode_common.h"
 
 // Phase markers for scripts/isa_budget.py (comments in the assembly: no instructions, no barriers beyond `volatile`).
@@ -37,6 +43,8 @@ namespace {
 constexpr u32 kR = 32;                  // input bytes per lane region
 constexpr u32 kW = SNP_WAVE * kR;       // the super-window
 constexpr u32 kCap = 128;               // a chain may overrun its region by this much before the wave takes over (multiple of 32)
+constexpr u32 kModeBatch = 0, kModeWindow = 1, kModeLongLiteral = 2, kModeLeave = 3;
+constexpr u32 kHist = 64;                // the stage keeps the output bytes just before the batch it holds: a copy of <= 64 bytes that starts there finds its source in LDS
 constexpr u32 kStage = 2048;            // output bytes of a batch (64 tags of <= 64 bytes could span 4096: a batch is cut at this)
 
 // Advance of the tag that starts with byte c, for the four bytes of a dword at once (Constants.cs:42-76: tag byte, 0..4 trailer bytes,
@@ -85,26 +93,28 @@ __device__ __forceinline__ void store_first_piece(u8* d, u32x4 p0, u32 len)
     }
 }
 
-// One lane copies len (1..64) bytes from s (global memory or the stage) into the stage at d: first and last 16 bytes (one round trip for
-// every tag of <= 32 bytes), then the two middle pieces of a longer one.  `any_mid`: some lane of the wave has len > 32 (wave-uniform: the
-// middle pieces are skipped by a scalar branch otherwise).
-__device__ __forceinline__ void copy_into_stage(u8* d, const u8* s, u32 len, bool any_mid)
+// One lane copies len (1..64) bytes into the stage at d in 16-byte pieces: first and last 16 bytes (every tag of <= 32 bytes), then the two middle
+// pieces of a longer one.  The LOADS (from global memory, or -- near copies -- from the stage while it still holds the previous batch) and the
+// STORES are apart: a batch's loads are in flight while the batch before it is finished.  `any_mid`: some lane of the wave has len > 32
+// (wave-uniform: the middle pieces are skipped by a scalar branch otherwise).
+__device__ __forceinline__ void load_pieces(const u8* s, u32 len, bool any_mid, u32x4& p0, u32x4& p1, u32x4& p2, u32x4& p3)
 {
-    const u32x4 p0 = ld128u(s);
-    u32x4 p1, p2, p3;                                                   // read only where they were loaded
+    p0 = ld128u(s);
     if (len > 16u) p1 = ld128u(s + len - 16);
-    const bool mid = len > 32u;
     if (any_mid) {
-        if (mid) {
+        if (len > 32u) {
             p2 = ld128u(s + 16);
             p3 = ld128u(s + min(32u, len - 16u));
-            asm volatile("" ::"v"(p2), "v"(p3));                        // (both in flight together: the compiler must not sink the second)
         }
     }
+}
+
+__device__ __forceinline__ void store_pieces(u8* d, u32 len, bool any_mid, const u32x4& p0, const u32x4& p1, const u32x4& p2, const u32x4& p3)
+{
     store_first_piece(d, p0, len);
     if (len > 16u) st128u(d + len - 16, p1);
     if (any_mid) {
-        if (mid) {
+        if (len > 32u) {
             st128u(d + 16, p2);
             if (len > 48u) st128u(d + 32, p3);
         }
@@ -117,8 +127,9 @@ template <bool FENCED, bool FRAG>
 __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
 {
     __shared__ __attribute__((aligned(16))) u8 c_tab[kW + 64];          // the advance table (+ 64 sentinels); afterwards the tag positions (u16 each, <= kW / 2 of them)
-    __shared__ __attribute__((aligned(16))) u8 c_stage[kStage + 64];    // a batch's output; while a super-window is built: flags, entries, overrun bitmaps
+    __shared__ __attribute__((aligned(16))) u8 c_stage_h[kHist + kStage + 64];    // a batch's output; while a super-window is built: flags, entries, overrun bitmaps
     __shared__ u64 c_busy[65];                                          // batches: pending output bytes; while a super-window is built: the tag-start map
+    u8* const c_stage = c_stage_h + kHist;                              // (the batch's first byte; up to h_hist bytes of history below it)
     u32* const c_T = reinterpret_cast<u32*>(c_busy);
     u16* const c_pos = reinterpret_cast<u16*>(c_tab);
     const u8* const src = B.src;
@@ -130,8 +141,162 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
     u32 wbase = B.ip, ntok = 0, emitted = 0, consumed = 0;
     u32 q_pf = 0;                                                       // tag bytes of the batch that starts at list index pf_at,
     u32 pf_at = ~0u;                                                    // requested while the batch before it executes
+    // The batch held back: its bytes are in the stage (pass 1 done), its waiting tags and its write-out run one trip later, under the next
+    // batch's loads.
+    bool h_valid = false;
+    u64 h_pend = 0;
+    u32 h_pk = 0, h_op = 0, h_span = 0, h_hist = 0;             // h_hist: valid history bytes below the held batch in the stage
+    // The held batch's waiting tags, in order (`fence`: no vmcnt(0) was waited for on the way here, and the slow form reads global memory).
+    auto finish_held = [&](const bool fence) __attribute__((always_inline)) {
+        lanes_sync_lds();
+        if (h_pend) {
+            if (FENCED && fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the slow form reads global memory)
+            const u32 vbase = lane + static_cast<u32>(reinterpret_cast<uintptr_t>(c_stage));   // LDS address of this lane's byte of a tag at stage offset 0
+            u64 pend = h_pend;
+            while (pend) {
+                u32 f, k;
+                // The plain form, hand-laid: 18 instructions per tag (the compiler's structured version of the same loop: 25 -- 3 % of the
+                // kernel, measured).  Pops tags off `pend` until it is empty or the popped tag (f, k < 0) needs the slow form below.  EXEC
+                // is restored before the block ends; the LDS operations of a wavefront execute in order, so a tag reads what the tag
+                // before it wrote.
+                {
+                    u32 t0, t1, t2, va, vb;
+                    u64 sv;
+                    asm volatile(
+                        "1:\n\t"
+                        "s_ff1_i32_b64 %[f], %[pend]\n\t"
+                        "v_readlane_b32 %[k], %[pk], %[f]\n\t"
+                        "s_bitset0_b64 %[pend], %[f]\n\t"
+                        "s_cmp_lt_i32 %[k], 0\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_bfe_u32 %[t0], %[k], 0x7000b\n\t"
+                        "s_lshr_b32 %[t1], %[k], 18\n\t"
+                        "s_and_b32 %[t2], %[k], 0x7ff\n\t"
+                        "v_cmp_gt_u32_e32 vcc, %[t0], %[lane]\n\t"
+                        "s_and_saveexec_b64 %[sv], vcc\n\t"
+                        "v_add_u32_e32 %[va], %[t1], %[vsrc]\n\t"
+                        "ds_read_u8 %[vb], %[va]\n\t"
+                        "v_add_u32_e32 %[va], %[t2], %[vbase]\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "ds_write_b8 %[va], %[vb]\n\t"
+                        "s_mov_b64 exec, %[sv]\n\t"
+                        "s_cmp_lg_u64 %[pend], 0\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "2:"
+                        : [pend] "+s"(pend), [f] "=&s"(f), [k] "=&s"(k), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(sv),
+                          [va] "=&v"(va), [vb] "=&v"(vb)
+                        : [pk] "v"(h_pk), [lane] "v"(lane), [vbase] "v"(vbase), [vsrc] "v"(vbase - kHist)
+                        : "vcc", "scc", "memory");
+                    if (static_cast<i32>(k) >= 0) break;            // (pend is empty)
+                }
+                // the slow form: a pattern copy (off < len: CopyHelpers.cs:222-230 copies byte by byte), or a source that starts below the batch
+                const u32 f_d = k & 0x7ffu, f_len = (k >> 11) & 0x7fu;
+                const u32 f_off = (k >> 18) & 0x1fffu;
+                const u32 sidx = f_off < f_len ? lane_mod(lane, f_off) : lane;
+                const u32 spos = f_d + sidx - f_off;                // from the batch's first byte; wraps when below it
+                // the source: the stage (the batch, or the history below it) -- or, when the history is shorter than the reach (a batch of
+                // < 64 bytes before this one: rare), global memory, on a scalar branch of its own so that only THAT path waits on vmcnt
+                u32 byte = 0;
+                if (__builtin_expect(static_cast<i32>(f_d - f_off) >= -static_cast<i32>(h_hist), 1)) {
+                    if (lane < f_len) byte = c_stage[static_cast<i32>(spos)];
+                } else {
+                    const bool below = static_cast<i32>(spos) < -static_cast<i32>(h_hist);
+                    if ((lane < f_len) & !below) byte = c_stage[static_cast<i32>(spos)];
+                    if ((lane < f_len) & below) byte = dst[h_op + spos];
+                    asm volatile("" : "+v"(byte));                      // (the vmcnt wait stays in this block: left pending, the compiler would
+                }                                                       //  wait at the loop's head, in every trip -- with the next batch's loads in flight)
+                if (lane < f_len) c_stage[f_d + lane] = static_cast<u8>(byte);
+                lanes_sync_lds();
+            }
+        }
+    };
+    auto write_out_held = [&]() __attribute__((always_inline)) {
+        // the whole run, coalesced, in 16-byte units: the last one may carry up to 15 stale bytes past the run -- every batch ends at least
+        // 16 bytes short of the block's end (`ok`), and what follows (the next batch, the serial loop) stores over them in order
+        lanes_sync_lds();
+        u8* const g = dst + h_op;
+        if (FRAG && h_op < skip) {                                  // the batch the fragment starts in: nothing before its first byte is written
+            for (u32 i = skip - h_op + lane; i < h_span; i += SNP_WAVE) g[i] = c_stage[i];
+        } else {
+            for (u32 i = lane * 16; i < h_span; i += SNP_WAVE * 16)
+                *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(c_stage + i);
+        }
+    };
     for (;;) {
-        if (emitted == ntok) {
+        // What this trip does: builds the next super-window (nothing may be held then), or takes the next batch of the list.
+        u32 mode = emitted == ntok ? kModeWindow : kModeBatch;
+        // the new batch (kModeBatch): what outlives the held batch's finish
+        u32 len = 0, off = 0, drel = 0, ne = 0, incl = 0, body = 0, s_first = 0, s_len0 = 0, s_body0 = 0;
+        bool is_lit = false, live = true;
+        if (mode == kModeBatch) {
+SNP_MARK(B_top);
+            // ---- one batch: the next <= 64 tags of the list ----
+            const u32 t = emitted + lane;
+            const bool have = t < ntok;
+            const u32 pos = c_pos[have ? t : emitted];                  // (idle lanes re-read the batch's first position)
+            // The tag bytes were requested a batch ago (q_pf); only the first batch of a super-window loads them here, and that load's wait
+            // stays on ITS path: merged at a join, the compiler would drain vmcnt in EVERY batch.
+            // (FOUR bytes per tag: a dword gather costs the texture path half of what the 8-byte one did, and only a copy-4 or a literal
+            //  with four length bytes -- which no 64 KiB-fragment compressor emits -- has a fifth byte: fetched below, when one shows up)
+            u32 q = q_pf;
+            if (pf_at != emitted) {
+                q = ld32u(src + wbase + pos);
+                asm volatile("" : "+v"(q));
+            }
+            const u32 c = q & 0xffu;
+            const u32 type = c & 3u;
+            const u32 hi6 = c >> 2;
+            u32 b1234 = q >> 8;
+            if (__builtin_expect(ballot64(have & ((type == 3u) | (c == 0xfcu))) != 0ull, 0)) {
+                if ((type == 3u) | (c == 0xfcu)) b1234 |= static_cast<u32>(src[wbase + pos + 4u]) << 24;
+            }
+            is_lit = type == 0;
+            const bool long_lit = is_lit && hi6 >= 60;
+            const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
+            const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
+            len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);
+            off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
+            body = pos + 1u + extra;                          // a literal's bytes, from wbase
+            const u32 olen = have ? len : 0u;
+            incl = wave_inclusive_scan(olen);
+            drel = incl - olen;                                         // the tag's first output byte, from the batch's
+            const u32 room = n - wbase - 16u;                           // load_pieces over-reads 15 bytes
+            const bool lit_ok = ((len - 1u) < room) & (body <= room - len);
+            const bool dead = FRAG && op + incl <= skip;                // ends at or before the fragment's start: parsed only
+            live = !FRAG || op + drel >= skip;
+            const bool copy_ok = (off - 1u) < op + drel - skip;
+            const bool ok = have & (dead ? (!is_lit | lit_ok) : live & ((is_lit & lit_ok) | (!is_lit & copy_ok))) & (incl + 16u <= expected - op);
+            const bool big = is_lit & (len > 64u);
+            const u64 okm = ballot64(ok & !big & (incl <= kStage));
+            ne = okm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~okm));
+SNP_MARK(B_ne0);
+            if (ne == 0) {
+                // not a batch: a literal > 64 bytes goes by the whole wave, anything else to the serial loop -- after the held batch
+                const u32 f0 = read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), 0);
+                mode = f0 == 3u ? kModeLongLiteral : kModeLeave;
+                s_first = read_lane(pos, 0);
+                s_len0 = read_lane(len, 0);
+                s_body0 = read_lane(body, 0) | (FRAG && read_lane(dead ? 1u : 0u, 0) ? 0x80000000u : 0u);
+            }
+        }
+        if (mode != kModeBatch) {
+            // Nothing is held across a window build (it uses the stage), a long literal or an exit.
+            if (h_valid) {
+                finish_held(true);
+                write_out_held();
+                h_valid = false;
+            }
+            if (mode == kModeLeave) {                                   // not ours: the serial loop decides, from this tag on
+                wbase += s_first;
+                consumed = 0;
+                break;
+            }
+            if (mode == kModeLongLiteral) {
+                if (!FRAG || static_cast<i32>(s_body0) >= 0) wave_copy(dst + op, src + wbase + (s_body0 & 0x7fffffffu), s_len0, lane);
+                op += s_len0;
+                emitted += 1;
+                continue;
+            }
             // ---- the next super-window ----
 SNP_MARK(S_stage_table);
             wbase += consumed;
@@ -270,144 +435,61 @@ SNP_MARK(T_list);
                 consumed = 0;
                 break;
             }
-        }
-SNP_MARK(B_top);
-        // ---- one batch: the next <= 64 tags of the list ----
-        const u32 t = emitted + lane;
-        const bool have = t < ntok;
-        const u32 pos = c_pos[have ? t : emitted];                      // (idle lanes re-read the batch's first position)
-        // The tag bytes were requested a batch ago (q_pf); only the first batch of a super-window loads them here, and that load's wait
-        // stays on ITS path: merged at a join, the compiler would drain vmcnt -- the previous batch's write-out -- in EVERY batch.
-        // (FOUR bytes per tag: a dword gather costs the texture path half of what the 8-byte one did, and only a copy-4 or a literal
-        //  with four length bytes -- which no 64 KiB-fragment compressor emits -- has a fifth byte: fetched below, when one shows up)
-        u32 q = q_pf;
-        if (pf_at != emitted) {
-            q = ld32u(src + wbase + pos);
-            asm volatile("" : "+v"(q));
-        }
-        const u32 c = q & 0xffu;
-        const u32 type = c & 3u;
-        const u32 hi6 = c >> 2;
-        u32 b1234 = q >> 8;
-        if (__builtin_expect(ballot64(have & ((type == 3u) | (c == 0xfcu))) != 0ull, 0)) {
-            if ((type == 3u) | (c == 0xfcu)) b1234 |= static_cast<u32>(src[wbase + pos + 4u]) << 24;
-        }
-        const bool is_lit = type == 0;
-        const bool long_lit = is_lit && hi6 >= 60;
-        const u32 extra = is_lit ? (long_lit ? hi6 - 59 : 0u) : (type == 3 ? 4u : type);
-        const u32 trailer = extra >= 4 ? b1234 : __builtin_amdgcn_ubfe(b1234, 0u, 8 * extra);
-        const u32 len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);
-        const u32 off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
-        const u32 body = pos + 1u + extra;                              // a literal's bytes, from wbase
-        const u32 olen = have ? len : 0u;
-        const u32 incl = wave_inclusive_scan(olen);
-        const u32 drel = incl - olen;                                   // the tag's first output byte, from the batch's
-        const u32 room = n - wbase - 16u;                               // copy_into_stage over-reads 15 bytes
-        const bool lit_ok = ((len - 1u) < room) & (body <= room - len);
-        const bool dead = FRAG && op + incl <= skip;                    // ends at or before the fragment's start: parsed only
-        const bool live = !FRAG || op + drel >= skip;
-        const bool copy_ok = (off - 1u) < op + drel - skip;
-        const bool ok = have & (dead ? (!is_lit | lit_ok) : live & ((is_lit & lit_ok) | (!is_lit & copy_ok))) & (incl + 16u <= expected - op);
-        const bool big = is_lit & (len > 64u);
-        const u64 okm = ballot64(ok & !big & (incl <= kStage));
-        const u32 ne = okm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~okm));
-SNP_MARK(B_ne0);
-        if (ne == 0) {
-            const u32 f0 = read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), 0);
-            if (f0 != 3u) {                                             // not ours: the serial loop decides, from this tag on
-                wbase += read_lane(pos, 0);
-                consumed = 0;
-                break;
-            }
-            const u32 l0 = read_lane(len, 0);
-            if (!FRAG || read_lane(dead ? 1u : 0u, 0) == 0u) wave_copy(dst + op, src + wbase + read_lane(body, 0), l0, lane);
-            op += l0;
-            emitted += 1;
             continue;
-        }
+    }
 SNP_MARK(B_pass1);
         const bool act = lane < ne;
         const u32 span = read_lane(incl, ne - 1);
-        const u32 srel = drel - off;                                    // source, from the batch's first byte (wraps when below it)
-        const bool ready = act & live & (is_lit | (off >= drel + len));   // copies: the source ends at or below the batch's first byte
-        if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pf_at = emitted + ne;                                           // the next batch's tag bytes travel with this batch's copies
+        // Where a copy's source lies (the held batch's bytes are in the stage, not yet in global memory):
+        //   far    ends at or below the held batch's first byte: global memory, loaded NOW -- the round trip runs under the held batch's finish;
+        //   near   inside the held batch: read from the stage once that batch is finished, before the stage is overwritten;
+        //   else   overlaps its own batch (or straddles the held batch's first byte: rare, the finish's slow form): waits, in order.
+        const u32 gap = h_valid ? op - h_op : 0u;
+        const u32 reach = drel + len;                           // off >= reach: the source ends at or below this batch's first byte
+        const u32 back = gap + (h_valid ? h_hist : 0u);                 // the stage holds this many bytes below this batch's first
+        const bool far = !is_lit & (off >= reach + gap);
+        const bool near = act & live & !is_lit & !far & (off >= reach) & (off <= drel + back);
+        const bool early = act & live & (is_lit | far);
+        const bool waits = act & live & !early & !near;
+        if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the write-outs before the held batch's are visible to this wave's loads
+        pf_at = emitted + ne;                                   // the next batch's tag bytes travel with this batch's loads
         if (pf_at < ntok) q_pf = ld32u(src + wbase + c_pos[pf_at + lane < ntok ? pf_at + lane : pf_at]);
-        u8* const my = c_stage + drel;
-        const u32 sofs_mine = is_lit ? wbase + body : op + srel;        // the source, from src (literals) or dst (copies)
         const bool any_mid = ballot64(act & (len > 32u)) != 0ull;
-        if (ready) copy_into_stage(my, (is_lit ? src : dst) + sofs_mine, len, any_mid);
+        const u32 sofs_mine = is_lit ? wbase + body : op + drel - off;   // the source, from src (literals) or dst (copies)
+        u32x4 p0, p1, p2, p3;                                           // read only where they were loaded
+        if (early) load_pieces((is_lit ? src : dst) + sofs_mine, len, any_mid, p0, p1, p2, p3);
 SNP_MARK(B_finish);
-        u64 pend = ballot64(act & live & !ready);
-        if (pend) {
-            const bool plain = (off >= len) & (off <= drel);            // not a pattern copy, source entirely inside the batch
-            // The rest in order, whole wave per tag, a byte per lane.  One packed word per tag (v_readlane): destination, length, and
-            // either the source inside the stage or a flag for the slow form (pattern copy, source that starts below the batch).
-            const u32 pk = drel | (len << 11) | (plain ? srel << 18 : 0x80000000u);
-            const u32 vbase = lane + static_cast<u32>(reinterpret_cast<uintptr_t>(c_stage));   // LDS address of this lane's byte of a tag at stage offset 0
-            while (pend) {
-                u32 f, k;
-                // The plain form, hand-laid: 18 instructions per tag (the compiler's structured version of the same loop: 25 -- and with every
-                // pending tag coming through here that is 3 % of the kernel, measured).  Pops tags off `pend` until it is empty or the popped
-                // tag (f, k < 0) needs the slow form below.  EXEC is restored before the block ends; the LDS operations of a wavefront
-                // execute in order, so a tag reads what the tag before it wrote.  (Two tags per trip -- both reads, then both writes, when the second
-                // does not read what the first writes -- measured SLOWER, 9.9 vs 9.7 ms: the round trip is not what the loop waits for.)
-                {
-                    u32 t0, t1, t2, va, vb;
-                    u64 sv;
-                    asm volatile(
-                        "1:\n\t"
-                        "s_ff1_i32_b64 %[f], %[pend]\n\t"
-                        "v_readlane_b32 %[k], %[pk], %[f]\n\t"
-                        "s_bitset0_b64 %[pend], %[f]\n\t"
-                        "s_cmp_lt_i32 %[k], 0\n\t"
-                        "s_cbranch_scc1 2f\n\t"
-                        "s_bfe_u32 %[t0], %[k], 0x7000b\n\t"
-                        "s_lshr_b32 %[t1], %[k], 18\n\t"
-                        "s_and_b32 %[t2], %[k], 0x7ff\n\t"
-                        "v_cmp_gt_u32_e32 vcc, %[t0], %[lane]\n\t"
-                        "s_and_saveexec_b64 %[sv], vcc\n\t"
-                        "v_add_u32_e32 %[va], %[t1], %[vbase]\n\t"
-                        "ds_read_u8 %[vb], %[va]\n\t"
-                        "v_add_u32_e32 %[va], %[t2], %[vbase]\n\t"
-                        "s_waitcnt lgkmcnt(0)\n\t"
-                        "ds_write_b8 %[va], %[vb]\n\t"
-                        "s_mov_b64 exec, %[sv]\n\t"
-                        "s_cmp_lg_u64 %[pend], 0\n\t"
-                        "s_cbranch_scc1 1b\n\t"
-                        "2:"
-                        : [pend] "+s"(pend), [f] "=&s"(f), [k] "=&s"(k), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [sv] "=&s"(sv),
-                          [va] "=&v"(va), [vb] "=&v"(vb)
-                        : [pk] "v"(pk), [lane] "v"(lane), [vbase] "v"(vbase)
-                        : "vcc", "scc", "memory");
-                    if (static_cast<i32>(k) >= 0) break;                // (pend is empty)
-                }
-                // the slow form: a pattern copy (off < len: CopyHelpers.cs:222-230 copies byte by byte), or a source that starts below the batch
-                const u32 f_d = k & 0x7ffu, f_len = (k >> 11) & 0x7fu;
-                const u32 f_off = read_lane(off, f);
-                const u32 sidx = f_off < f_len ? lane_mod(lane, f_off) : lane;
-                const u32 spos = f_d + sidx - f_off;                    // from the batch's first byte; wraps when below it
-                u32 byte = 0;
-                if (lane < f_len) {
-                    if (static_cast<i32>(spos) < 0) byte = dst[op + spos];          // (two branches: one select would make this a flat load)
-                    else byte = c_stage[spos];
-                }
-                if (lane < f_len) c_stage[f_d + lane] = static_cast<u8>(byte);
-                lanes_sync_lds();
-            }
-        }
+        if (h_valid) finish_held(false);
 SNP_MARK(B_writeout);
-        // the whole run, coalesced, in 16-byte units: the last one may carry up to 15 stale bytes past the run -- every batch ends at least
-        // 16 bytes short of the block's end (`ok`), and what follows (the next batch, the serial loop) stores over them in order
-        lanes_sync_lds();
-        u8* const g = dst + op;
-        if (FRAG && op < skip) {                                        // the batch the fragment starts in: nothing before its first byte is written
-            for (u32 i = skip - op + lane; i < span; i += SNP_WAVE) g[i] = c_stage[i];
-        } else {
-            for (u32 i = lane * 16; i < span; i += SNP_WAVE * 16)
-                *reinterpret_cast<snp_u128_unaligned*>(g + i) = *reinterpret_cast<const snp_u128_unaligned*>(c_stage + i);
+        // This batch's loads are back by now (they had the finish to travel in): waited for HERE, before the write-out's stores join the
+        // queue behind them -- past this point the compiler sees fresh values and has no reason to drain the stores with them.
+        asm volatile("; loads of the new batch are back"
+                     :: "v"(p0.x), "v"(p0.y), "v"(p0.z), "v"(p0.w), "v"(p1.x), "v"(p1.y), "v"(p1.z), "v"(p1.w), "v"(p2.x), "v"(p2.y), "v"(p2.z),
+                        "v"(p2.w), "v"(p3.x), "v"(p3.y), "v"(p3.z), "v"(p3.w), "v"(q_pf)
+                     : "memory");
+        if (h_valid) write_out_held();
+SNP_MARK(B_stage);
+        // ---- the new batch into the stage (the held batch has left it): near copies read their source there first ----
+        if (near) load_pieces(c_stage + static_cast<i32>(drel + gap - off), len, any_mid, p0, p1, p2, p3);
+        // the history for THIS batch: the last 64 bytes of what the stage holds (history + held batch), moved below the batch's first byte
+        const u32 hist = h_valid ? min(kHist, h_hist + gap) : 0u;
+        if (hist) {
+            const u8 hb = c_stage[static_cast<i32>(gap + lane - kHist)];
+            if (lane >= kHist - hist) c_stage[static_cast<i32>(lane - kHist)] = hb;
         }
-        lanes_sync_lds();
+        if (early | near) store_pieces(c_stage + drel, len, any_mid, p0, p1, p2, p3);
+        {
+            // The rest waits for the next trip, in order, whole wave per tag, a byte per lane.  One packed word per tag (v_readlane): destination,
+            // length, and either the source inside the stage or a flag for the slow form (pattern copy, source that starts below the batch).
+            const bool plain = (off >= len) & (off <= drel + hist);     // not a pattern copy, source inside the batch or the history below it
+            h_pend = ballot64(waits);
+            h_pk = drel | (len << 11) | (plain ? (drel - off + kHist) << 18 : 0x80000000u | (off << 18));   // (plain: the source, counted from the
+                                                                        //  history's first byte; slow: the offset -- a waiting tag's is < drel + len + 64)
+            h_op = op;
+            h_span = span;
+            h_hist = hist;
+            h_valid = true;
+        }
         op += span;
         emitted += ne;
     }
