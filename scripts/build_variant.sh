@@ -7,7 +7,7 @@
 #                                                          SNAPPIER_HIP_* knobs act: the product library reads no environment)
 #     LAB=1 CLAB=1 SRC=compress_lanes.hip scripts/build_variant.sh clablate -DSNP_CL_ABLATE_RT=1
 #                                                          ... with lab/compress_lanes_r04.hip (the lane compressor with its timing-only ablations)
-#     PATCH=scripts/lab_patches/decode_chains_prof_abl.patch scripts/build_variant.sh prof -DSNP_DC_PROF=1
+#     PATCH=scripts/lab_patches/decode_chains_prof.patch scripts/build_variant.sh prof -DSNP_DC_PROF=1
 #                                                          the varied source is a patched COPY (/tmp): instrumentation that never enters the product
 #                                                          source (per-phase shader-clock budget: scripts/r5_decode_prof.py; -DSNP_DC_ABL=mask: timing-only removals)
 set -e
