@@ -104,9 +104,10 @@ typedef enum snp_option {
     SNP_OPT_SMALL_BLOCK_MIN_BATCH = 3,  /* ... in batches of at least this many blocks (default 4096) */
     /* snp_compress_batch: 0 (default) by batch size -- below SNP_OPT_COMPRESS_WINDOW_MAX_BATCH fragments one fragment per wavefront
      * with the hash table in LDS, from there on one fragment per lane with the tables in an HBM workspace; 2 / 3 pin the latter / former;
-     * 4 = the per-wavefront kernel with its table in a global-memory slot instead of LDS (measured +5 % only: never chosen by itself). */
+     * 4 = the per-wavefront kernel with its table in a global-memory slot instead of LDS (+5 % from 4 096 fragments up, where layout 0 takes it:
+     * 32 wavefronts per CU instead of 5; slower below). */
     SNP_OPT_COMPRESS_LAYOUT = 4,
-    SNP_OPT_COMPRESS_WINDOW_MAX_BATCH = 5,   /* default 16384 */
+    SNP_OPT_COMPRESS_WINDOW_MAX_BATCH = 5,   /* default 20480 */
     /* The lane compressor keeps 64 KiB of hash table per fragment of a launch in an HBM workspace (10.7 GB for 163 840 fragments; batches
      * above 262 144 fragments run in slices).  The workspace belongs to the DEVICE, not to the context: every context on a device borrows the
      * same one for the duration of a launch sequence (a GPU-side event orders the borrowers; no host thread blocks), so eight caller
@@ -199,7 +200,7 @@ snp_status snp_frame_decode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* 
 /* Stream capture: snp_compress_batch, snp_decompress_batch, snp_crc32c_batch and snp_frame_encode_device only enqueue kernels, so they may be called while the context's
  * stream is being captured into a hipGraph and replayed later (the graph reads the device arrays as they are at replay time).  A captured call
  * queries, synchronises and allocates nothing; it therefore needs the workspaces to exist already -- make the same call once before
- * the capture (compress of >= 16 384 fragments: or snp_ctx_reserve_compress).  A call that would have to allocate during a capture returns
+ * the capture (compress keeps a workspace from 4 096 fragments on; from 20 480 on snp_ctx_reserve_compress builds it too).  A call that would have to allocate during a capture returns
  * SNP_ERR_DEVICE (snp_ctx_last_error says so) and leaves the capture valid.  The host-pointer entry points synchronise and cannot be captured.
  * LIFETIME: a captured graph holds the addresses of the workspaces it ran on.  From the first captured call on, the context (and the device's
  * table pool) never frees a workspace it has handed out -- a later, larger call allocates a new one next to it -- until snp_ctx_destroy; a graph
@@ -210,8 +211,8 @@ snp_status snp_frame_decode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* 
  * block b reads in[in_off[b] .. +in_len[b]) and writes  varint(in_len[b]) || CompressFragment  at
  * out[out_off[b] ..), which must have room for snp_max_compressed_length(in_len[b]) bytes.
  * out_len[b] = bytes written, status[b] = SNP_OK | SNP_ERR_BAD_ARG (in_len[b] > 65536).
- * Layout by batch size: below 16 384 fragments one fragment per wavefront with the u16 hash table in LDS
- * (compress_win.hip), from there on one fragment per LANE with the tables in an HBM workspace the context owns
+ * Layout by batch size: below 20 480 fragments one fragment per wavefront with the u16 hash table in LDS -- from 4 096 fragments on in a
+ * global-memory slot that stays cache-resident -- (compress_win.hip), from there on one fragment per LANE with the tables in an HBM workspace the context owns
  * (compress_lanes.hip); both emit the reference's bytes.  All arrays are device memory. */
 snp_status snp_compress_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,
                               uint32_t nblocks, uint8_t* out, const uint64_t* out_off, uint32_t* out_len,

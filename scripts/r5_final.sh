@@ -4,7 +4,7 @@
 # library), compress by batch size, host API, small blocks, PMC passes of the decoder.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=${TAG:-r05z}
+T=${TAG:-r05zz}
 (timeout 200 python __graft_entry__.py smoke > gpurun_out/${T}_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/${T}_smoke.log); tail -2 gpurun_out/${T}_smoke.log
 timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/${T}_pytest.log 2>&1; tail -2 gpurun_out/${T}_pytest.log
 timeout 600 python bench.py > gpurun_out/${T}_bench_line.json 2> gpurun_out/${T}_bench.err; tail -c 300 gpurun_out/${T}_bench_line.json; echo

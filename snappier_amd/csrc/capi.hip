@@ -160,9 +160,11 @@ struct snp_ctx {
     bool redo_grid = false, redo_list = false;   // SNAPPIER_HIP_REDO=grid|list pins how the pre-pass's leftovers are decoded (default: by how the previous batch went)
     u32 small_team_log = 0;        // SNAPPIER_HIP_SMALL=team4|team8|team16: lanes per block (0 = the kernel's default)
     u32 slice_fragments = 262144;   // fragments per lane-compressor launch (SNAPPIER_HIP_SLICE pins it)
-    u32 win_gtab_min = 0xffffffffu;   // auto mode: window-kernel batches of at least this many fragments would keep their tables in global memory (SNAPPIER_HIP_WIN_GTAB_MIN);
+    u32 win_gtab_min = 4096; // auto mode: window-kernel batches of at least this many fragments keep their tables in global memory (SNAPPIER_HIP_WIN_GTAB_MIN):
+                             // 36.5 vs 34.6 GB/s from 4 096 fragments up, 19.8 vs 35.5 at 1 024 (profiles/r05zz_compress_by_batch.jsonl);
                                       // never by default: measured +5 % only (36.4 vs 34.6 GB/s at 4 096-16 383 fragments -- the kernel turns texture-path-bound, profiles/r04k_pmc_window_kernel.txt)
-    u32 win_max = 16384;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX)
+    u32 win_max = 20480;     // auto mode: batches below this many fragments take the window kernel (SNAPPIER_HIP_WIN_MAX): the lane kernel needs its
+                             // ~31-37 ms whatever the count up to ~20 000 fragments (16 384: 33.0 GB/s against the window kernel's 36.5; 20 480: 35.9 against 35.7; 32 768: 52.2 against 36.3)
     DevBuf in, out, meta, work, fragtab, scan, small, redo, win_tables;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
     uint64_t counters[6] = {0, 0, 0, 0, 0, 0};   // snp_ctx_counter

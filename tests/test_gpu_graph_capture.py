@@ -28,9 +28,9 @@ def _oracle_lengths(raw: torch.Tensor, nb: int, variant: int):
     return ref, ref_off.astype(np.int64), ref_len.astype(np.int64)
 
 
-@pytest.mark.parametrize("nb,layout", [(64, None), (4096, None), (20000, None), (20000, "ring")])
+@pytest.mark.parametrize("nb,layout", [(64, None), (4096, None), (24000, None), (24000, "ring")])
 def test_batch_calls_replay_from_a_graph_with_the_oracles_bytes(nb, layout, monkeypatch):
-    monkeypatch.setenv("SNAPPIER_HIP_TABLE_TRIES", "1")                       # (20 000 fragments: a 1.3 GB workspace, no placement search in a test)
+    monkeypatch.setenv("SNAPPIER_HIP_TABLE_TRIES", "1")                       # (24 000 fragments: the lane compressor, a 1.6 GB workspace, no placement search in a test)
     if layout:
         monkeypatch.setenv("SNAPPIER_HIP_DECODE", layout)
     html = read_testdata("html")

@@ -1051,12 +1051,12 @@ def test_frame_decode_takes_chunks_beyond_64_kib_like_the_reference():
 
 def test_two_threads_share_the_devices_table_pool():
     """the lane compressor's hash-table workspace belongs to the device.  Two caller threads, a context each, compress
-    >= 16 384 fragments each at the same time: the bytes equal the oracle's, and the library allocates ONE workspace (plus its bounded
+    lane-compressor batches (>= 20 480 fragments each) at the same time: the bytes equal the oracle's, and the library allocates ONE workspace (plus its bounded
     search: at most a second workspace's worth of candidates, transiently), not one per context."""
     import gc
     import threading
     gc.collect()                                                            # (contexts of earlier tests: the device's pool dies with the last of them)
-    nb = 20480                                                              # 1.25 GiB of tables per launch: the searched (pieces) form
+    nb = 22528                                                              # 1.4 GiB of tables per launch: the searched (pieces) form
     html = read_testdata("html")
     raws = [SD.html_like_blocks(html, 1000 * t, nb, "cuda") for t in range(2)]
     cds = [SB.BlockCodec(0, O.HASH_CRC32C) for _ in range(2)]
