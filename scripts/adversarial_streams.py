@@ -68,13 +68,39 @@ def build(kind, total=65536):
         while produced + 5 <= total:
             emit(lit(b"x"), 1)
             emit(copy4(4, 8), 4)
+    elif kind == "edge_sweep":                  # built against the TWO-BATCH execution (decode_chains.hip): 1-byte literals and copies whose (offset, length)
+        import random                           # sweep every relation to a batch of 64 tags -- source ends / starts at the held batch's first byte, in the
+        rnd = random.Random(7)                  # 64 bytes of history below it, one byte beyond the history, inside the own batch, pattern copies
+        emit(lit(bytes(range(200))), 200)
+        k = 0
+        while produced + 70 <= total:
+            if k % 3 == 0:
+                emit(lit(bytes([rnd.randrange(256)])), 1)
+            else:
+                ln = 1 + (k * 7) % 64
+                off = min(produced, 1 + (k * 13) % 260 if k % 5 else rnd.choice((1, 2, 3, 5, 63, 64, 65, 66, 127, 128, 129)))
+                emit(copy2(ln, off), ln)
+            k += 1
+    elif kind == "long_literals_between_batches":   # literals of 65..130 bytes (copied by the whole wave, nothing held across them) between short runs of
+        import random                               # copies that reach back over them: the first batch after a drain has no history in the stage
+        rnd = random.Random(11)
+        emit(lit(bytes(range(100))), 100)
+        k = 0
+        while produced + 400 <= total:
+            n = 65 + (k * 5) % 66
+            emit(lit(bytes((k + i) & 255 for i in range(n))), n)
+            for j in range(1 + k % 7):
+                ln = 4 + (k + 3 * j) % 61
+                off = min(produced, (1, 3, 60, 64, 65, 70, 130, 131, 200)[(k + j) % 9])
+                emit(copy2(ln, off), ln)
+            k += 1
     if produced < total:
         emit(lit(bytes(total - produced)), total - produced)
     return varint(total) + bytes(out)
 
 
 KINDS = ("copy4_len4_period5", "copy4_len64_period5", "literals_of_f4", "literals_of_ff_period61", "literals_of_14_period7",
-         "copy2_offsets_f4f4", "period7_mix")
+         "copy2_offsets_f4f4", "period7_mix", "edge_sweep", "long_literals_between_batches")
 
 
 def main():
