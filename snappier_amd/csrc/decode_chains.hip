@@ -150,6 +150,7 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
     auto finish_held = [&](const bool fence) __attribute__((always_inline)) {
         lanes_sync_lds();
         if (h_pend) {
+            if (FENCED && fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the slow form reads global memory)
             const u32 vbase = lane + static_cast<u32>(reinterpret_cast<uintptr_t>(c_stage));   // LDS address of this lane's byte of a tag at stage offset 0
             u64 pend = h_pend;
             while (pend) {
@@ -200,7 +201,6 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
                     if (lane < f_len) byte = c_stage[static_cast<i32>(spos)];
                 } else {
                     const bool below = static_cast<i32>(spos) < -static_cast<i32>(h_hist);
-                    if (FENCED && fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (earlier write-outs are visible to this read)
                     if ((lane < f_len) & !below) byte = c_stage[static_cast<i32>(spos)];
                     if ((lane < f_len) & below) byte = dst[h_op + spos];
                     asm volatile("" : "+v"(byte));                      // (the vmcnt wait stays in this block: left pending, the compiler would
@@ -280,13 +280,7 @@ SNP_MARK(B_ne0);
             }
         }
         if (mode != kModeBatch) {
-            // Nothing is held across a window build (it uses the stage), a long literal or an exit.  A long literal of <= 256 bytes (plain text
-            // is full of them) asks for its bytes first, a dword per lane: the round trip runs under the held batch's finish.
-            u32 lw = 0;
-            const bool lit_quick = mode == kModeLongLiteral && s_len0 <= 256u && (!FRAG || static_cast<i32>(s_body0) >= 0);
-            if (lit_quick) {
-                if (lane * 4u < s_len0) lw = ld32u(src + wbase + (s_body0 & 0x7fffffffu) + lane * 4u);   // (`ok`: 16 readable bytes past the literal's end)
-            }
+            // Nothing is held across a window build (it uses the stage), a long literal or an exit.
             if (h_valid) {
                 finish_held(true);
                 write_out_held();
@@ -298,11 +292,7 @@ SNP_MARK(B_ne0);
                 break;
             }
             if (mode == kModeLongLiteral) {
-                if (lit_quick) {                                        // (the last dword may carry <= 3 bytes past the literal: `ok` left 16 of room, later stores overwrite them)
-                    if (lane * 4u < s_len0) st32u(dst + op + lane * 4u, lw);
-                } else if (!FRAG || static_cast<i32>(s_body0) >= 0) {
-                    wave_copy(dst + op, src + wbase + (s_body0 & 0x7fffffffu), s_len0, lane);
-                }
+                if (!FRAG || static_cast<i32>(s_body0) >= 0) wave_copy(dst + op, src + wbase + (s_body0 & 0x7fffffffu), s_len0, lane);
                 op += s_len0;
                 emitted += 1;
                 continue;
