@@ -141,7 +141,7 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
     u32 wbase = B.ip, ntok = 0, emitted = 0, consumed = 0;
     u32 q_pf = 0;                                                       // tag bytes of the batch that starts at list index pf_at,
     u32 pf_at = ~0u;                                                    // requested while the batch before it executes
-    // The batch held back: its bytes are in the stage (pass 1 done), its waiting tags and its write-out run one trip later, under the next
+    // The batch held back: its bytes are in the stage (every piece stored), its waiting tags and its write-out run one trip later, under the next
     // batch's loads.
     bool h_valid = false;
     u64 h_pend = 0;
