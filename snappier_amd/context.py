@@ -38,7 +38,8 @@ class Context:
         return self._h
 
     def counter(self, which: int) -> int:
-        """snp_ctx_counter: 0 = large blocks decoded per fragment, 1 = large blocks that fell back to one wavefront."""
+        """snp_ctx_counter: 0 = large blocks decoded per fragment, 1 = large blocks that fell back to one wavefront, 6 = tag indexes that needed
+        the look-back pass (2..5: the table workspace search)."""
         return int(self.lib.snp_ctx_counter(self._h, which))
 
     def set_option(self, option: int, value: int):

@@ -23,6 +23,8 @@ extern "C" {
 hipError_t snp_launch_decompress(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*,
                                  const u8*, int, hipStream_t, const u32*);
 u32 snp_tag_index_entries(u32, u32);
+size_t snp_tag_index_workspace_bytes(u32, u32);
+size_t snp_tag_index_fallback_offset(u32, u32);
 hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
                                    hipStream_t, uint16_t*, u32);
@@ -167,7 +169,7 @@ struct snp_ctx {
                              // ~31-37 ms whatever the count up to ~20 000 fragments (16 384: 33.0 GB/s against the window kernel's 36.5; 20 480: 35.9 against 35.7; 32 768: 52.2 against 36.3)
     DevBuf in, out, meta, work, fragtab, scan, small, redo, win_tables;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial
-    uint64_t counters[6] = {0, 0, 0, 0, 0, 0};   // snp_ctx_counter
+    uint64_t counters[7] = {0, 0, 0, 0, 0, 0, 0};   // snp_ctx_counter
     bool table_tries_set = false;   // SNP_OPT_TABLE_PROBE_TRIES / SNAPPIER_HIP_TABLE_TRIES was given: the implicit in-call search honours it as is
     std::string err;
 
@@ -700,7 +702,7 @@ snp_status snp_ctx_create(int device, int hash_variant, void* stream, snp_ctx** 
     return SNP_OK;
 }
 
-uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 6) ? c->counters[which] : 0; }
+uint64_t snp_ctx_counter(const snp_ctx* c, int which) { return (c && which >= 0 && which < 7) ? c->counters[which] : 0; }
 
 snp_status snp_ctx_reserve_compress(snp_ctx* c, uint32_t nfragments)
 {
@@ -1216,7 +1218,7 @@ snp_status decompress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uin
             const u32 nent = snp_tag_index_entries(static_cast<u32>(n), hb);
             const u32 nf = (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
             // fragment table: in_off, out_off (u64) ; in_len, out_cap, skip, out_len (u32) ; status (i32)
-            if (!c->ensure(c->work, static_cast<size_t>(nent) * 8 + 16, "hipMalloc(tag index)") ||
+            if (!c->ensure(c->work, snp_tag_index_workspace_bytes(static_cast<u32>(n), hb), "hipMalloc(tag index)") ||
                 !c->ensure(c->fragtab, static_cast<size_t>(nf) * (8 * 2 + 4 * 5), "hipMalloc(fragment table)"))
                 return SNP_ERR_DEVICE;
             u64* f_in_off = static_cast<u64*>(c->fragtab.p);
@@ -1234,12 +1236,16 @@ snp_status decompress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uin
                                                       nullptr, c->fenced | ((c->dec_lds / 256) << 8), s, f_skip),
                                 "decompress fragments");
             std::vector<i32> st(nf);
+            u32 looked_back = 0;
             ok = ok && c->check(hipMemcpyAsync(st.data(), f_status, nf * 4ull, hipMemcpyDeviceToHost, s), "D2H status");
+            ok = ok && c->check(hipMemcpyAsync(&looked_back, static_cast<const u8*>(c->work.p) + snp_tag_index_fallback_offset(static_cast<u32>(n), hb), 4,
+                                               hipMemcpyDeviceToHost, s), "D2H tag-index flag");
             ok = ok && c->check(hipStreamSynchronize(s), "sync");
             if (!ok) return SNP_ERR_DEVICE;
             bool all_ok = true;
             for (u32 f = 0; f < nf; ++f) all_ok = all_ok && st[f] == SNP_OK;
             ++c->counters[all_ok ? 0 : 1];
+            if (looked_back) ++c->counters[6];
             if (!all_ok && SNP_GETENV("SNAPPIER_HIP_DEBUG")) {
                 std::vector<u64> ent(nent), fo(nf);
                 std::vector<u32> sk(nf), il(nf);
