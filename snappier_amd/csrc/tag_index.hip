@@ -43,17 +43,27 @@ constexpr u32 kFar = 0xfffffffeu;                 // table: next-pointer not rep
 __device__ __forceinline__ u64 pack(u32 sum, u32 next) { return (static_cast<u64>(sum) << 32) | next; }
 
 // Steps 1a + 1b for the chunk at stream offset `base`: T[j] = (output bytes, first tag start at or after the end of j's sub-chunk).
-__device__ __forceinline__ void build_table(u64* T, const u8* __restrict__ src, const u32 n, const u64 base)
+__device__ __forceinline__ void build_table(u64* T, u8* raw, const u8* __restrict__ src, const u32 n, const u64 base)
 {
     // ---- 1a. the tag that would start at every position ----------------------------------------------------------
+    // the chunk's bytes (+ 8: a tag's trailer may reach into the next chunk; zeros past the end of the stream) come in once, 16 per thread, and
+    // every position reads its 8 from LDS (16 384 overlapping 8-byte gathers from global memory were a third of this function)
+    static_assert(kThreads * 16 == kChunk, "one 16-byte piece per thread");
+    {
+        const u64 p = base + threadIdx.x * 16u;
+        snp_u128_unaligned v = {{0, 0, 0, 0}};
+        if (p + 16 <= n) v = *reinterpret_cast<const snp_u128_unaligned*>(src + p);
+        else
+            for (u32 i = 0; i < 16 && p + i < n; ++i) reinterpret_cast<u8*>(&v)[i] = src[p + i];
+        *reinterpret_cast<snp_u128_unaligned*>(raw + threadIdx.x * 16u) = v;
+        if (threadIdx.x < 8) raw[kChunk + threadIdx.x] = base + kChunk + threadIdx.x < n ? src[base + kChunk + threadIdx.x] : u8{0};
+    }
+    __syncthreads();
     for (u32 j = threadIdx.x; j < kChunk; j += kThreads) {
         const u64 pos = base + j;
         u64 e = pack(0, kFar);
         if (pos < n) {
-            u64 q = 0;
-            if (pos + 8 <= n) q = ld64u(src + pos);
-            else
-                for (u32 i = 0; pos + i < n; ++i) q |= static_cast<u64>(src[pos + i]) << (8 * i);
+            const u64 q = ld64u(raw + j);
             const u32 c = static_cast<u32>(q) & 0xffu;
             const u32 type = c & 3u;
             const u32 hi6 = c >> 2;
@@ -73,6 +83,7 @@ __device__ __forceinline__ void build_table(u64* T, const u8* __restrict__ src, 
     __syncthreads();
     // ---- 1b. pointer doubling inside each 4 KiB sub-chunk (in place: any value a reader sees is a valid jump) -----
     for (u32 r = 0; r < kRounds; ++r) {
+#pragma unroll 4
         for (u32 j = threadIdx.x; j < kChunk; j += kThreads) {
             const u64 e = T[j];
             const u32 nx = static_cast<u32>(e);
@@ -110,6 +121,7 @@ __global__ __launch_bounds__(kThreads) void k_tag_index(const u8* __restrict__ s
                                                   u64* __restrict__ entries, u32* __restrict__ ticket, const u32* __restrict__ wanted)
 {
     __shared__ u64 T[kChunk];
+    __shared__ __attribute__((aligned(16))) u8 s_raw[kChunk + 16];
     __shared__ u32 s_chunk;
     if (__hip_atomic_load(wanted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // (the fallback: k_tag_scan found every entry among the candidates)
     if (threadIdx.x == 0) s_chunk = atomicAdd(ticket, 1u);
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(kThreads) void k_tag_index(const u8* __restrict__ s
     if (k >= nchunks) return;
     const u64 base = hb + static_cast<u64>(k) * kChunk;               // stream offset of this chunk
 
-    build_table(T, src, n, base);
+    build_table(T, s_raw, src, n, base);
     // ---- 2. look-back: the true entry of this chunk, through its sub-chunks, to the entry of the next chunk -------
     if (threadIdx.x == 0) {
         u64 ent;
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(kThreads) void k_tag_cand(const u8* __restrict__ sr
                                                  CandHandoff* __restrict__ hand, u32* __restrict__ ticket)
 {
     __shared__ u64 T[kChunk];
+    __shared__ __attribute__((aligned(16))) u8 s_raw[kChunk + 16];
     __shared__ u32 s_chunk;
     __shared__ u32 s_land[kProbe];
     __shared__ u32 s_ncand;
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void k_tag_cand(const u8* __restrict__ sr
     if (k >= nchunks) return;
     const u64 base = hb + static_cast<u64>(k) * kChunk;
     const u64 end = base + kChunk;
-    build_table(T, src, n, base);
+    build_table(T, s_raw, src, n, base);
     // where the walks that enter at the chunk's first bytes leave it: the next chunk's candidate entries
     if (threadIdx.x < kProbe) {
         u32 rip[kSubs + 1], rop[kSubs + 1];
