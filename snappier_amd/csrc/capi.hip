@@ -26,6 +26,10 @@ u32 snp_tag_index_entries(u32, u32);
 size_t snp_tag_index_workspace_bytes(u32, u32);
 size_t snp_tag_index_fallback_offset(u32, u32);
 hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
+u32 snp_tag_index_chunks_ready(u32, u32, u64);
+hipError_t snp_launch_tag_index_begin(u64*, u32, u32, hipStream_t);
+hipError_t snp_launch_tag_index_chunks(const u8*, u32, u32, u64*, u32, u32, hipStream_t);
+hipError_t snp_launch_tag_index_finish(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
                                    hipStream_t, uint16_t*, u32);
 size_t snp_compress_win_table_bytes(u32);
@@ -1198,29 +1202,53 @@ snp_status decompress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uin
     struct Meta { u64 in_off, out_off; u32 in_len, out_cap, out_len; i32 status; } h{0, 0, static_cast<u32>(n), cap32, 0, 0};
     u8* m = static_cast<u8*>(c->meta.p);
     bool ok = c->check(hipMemcpyAsync(m, &h, sizeof(h), hipMemcpyHostToDevice, s), "H2D meta");
-    if (n) ok = ok && in_spans.upload(c, c->in.p);
 
     // A large block: one wavefront per 64 KiB output fragment, fragment starts from the tag index (tag_index.hip).
     // Taken only for a clean preamble that fits the output; any fragment that does not come back OK (foreign streams
     // whose copies cross fragments, malformed data) sends the whole block to the single-wavefront decoder below.
-    {
-        u32 expected = 0, hb = 0, shift = 0;
-        bool clean = false;
-        for (u32 i = 0; i < 5 && i < n; ++i) {                            // VarIntEncoding.Read.cs:38-79
-            const u32 ch = in[i], val = ch & 0x7fu;
-            if (val & ~(0xffffffffu >> shift)) break;
-            expected |= val << shift;
-            shift += 7;
-            hb = i + 1;
-            if (ch < 128) { clean = true; break; }
+    u32 expected = 0, hb = 0, shift = 0;
+    bool clean = false;
+    for (u32 i = 0; i < 5 && i < n; ++i) {                                // VarIntEncoding.Read.cs:38-79
+        const u32 ch = in[i], val = ch & 0x7fu;
+        if (val & ~(0xffffffffu >> shift)) break;
+        expected |= val << shift;
+        shift += 7;
+        hb = i + 1;
+        if (ch < 128) { clean = true; break; }
+    }
+    const bool large = clean && c->par_min && expected >= c->par_min && expected <= cap32 && n > hb;
+    const u32 nf = large ? (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE : 0;
+    // fragment table: in_off, out_off (u64) ; in_len, out_cap, skip, out_len (u32) ; status (i32)
+    if (large && (!c->ensure(c->work, snp_tag_index_workspace_bytes(static_cast<u32>(n), hb), "hipMalloc(tag index)") ||
+                  !c->ensure(c->fragtab, static_cast<size_t>(nf) * (8 * 2 + 4 * 5), "hipMalloc(fragment table)")))
+        return SNP_ERR_DEVICE;
+    // The upload.  One large stream from one host buffer goes up in slices on the copy stream, and the tag index's per-chunk pass (most of its
+    // time, and independent chunk by chunk) runs on each slice as it lands.
+    bool indexed = false;
+    if (ok && n && large && in_spans.count == 1 && n >= (8u << 20) && c->copy_stream_ready()) {
+        const u8* const host_in = in_spans.ptr[0];
+        const size_t slice = n / 8 > (4u << 20) ? (n / 8 + 4095) / 4096 * 4096 : (4u << 20);
+        ok = c->check(snp_launch_tag_index_begin(static_cast<u64*>(c->work.p), static_cast<u32>(n), hb, s), "tag index") &&
+             c->check(hipEventRecord(c->copy_ev[0], s), "event") && c->check(hipStreamWaitEvent(c->copy_stream, c->copy_ev[0], 0), "wait");
+        u32 done_chunks = 0, k = 0;
+        for (size_t off = 0; off < n && ok; off += slice, ++k) {
+            const size_t len = n - off < slice ? n - off : slice;
+            hipEvent_t ev = c->copy_ev[k & 1];
+            const u32 ready = snp_tag_index_chunks_ready(static_cast<u32>(n), hb, off + len);
+            ok = c->check(hipMemcpyAsync(static_cast<u8*>(c->in.p) + off, host_in + off, len, hipMemcpyHostToDevice, c->copy_stream), "H2D input") &&
+                 c->check(hipEventRecord(ev, c->copy_stream), "event") && c->check(hipStreamWaitEvent(s, ev, 0), "wait") &&
+                 c->check(snp_launch_tag_index_chunks(static_cast<const u8*>(c->in.p), static_cast<u32>(n), hb, static_cast<u64*>(c->work.p),
+                                                      done_chunks, ready - done_chunks, s), "tag index");
+            done_chunks = ready;
         }
-        if (ok && clean && c->par_min && expected >= c->par_min && expected <= cap32 && n > hb) {
+        if (!ok) (void)hipStreamSynchronize(c->copy_stream);              // (the caller may free its buffer at once: no copy from it may be in flight)
+        indexed = ok;
+    } else if (n) {
+        ok = ok && in_spans.upload(c, c->in.p);
+    }
+    {
+        if (ok && large) {
             const u32 nent = snp_tag_index_entries(static_cast<u32>(n), hb);
-            const u32 nf = (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
-            // fragment table: in_off, out_off (u64) ; in_len, out_cap, skip, out_len (u32) ; status (i32)
-            if (!c->ensure(c->work, snp_tag_index_workspace_bytes(static_cast<u32>(n), hb), "hipMalloc(tag index)") ||
-                !c->ensure(c->fragtab, static_cast<size_t>(nf) * (8 * 2 + 4 * 5), "hipMalloc(fragment table)"))
-                return SNP_ERR_DEVICE;
             u64* f_in_off = static_cast<u64*>(c->fragtab.p);
             u64* f_out_off = f_in_off + nf;
             u32* f_in_len = reinterpret_cast<u32*>(f_out_off + nf);
@@ -1228,9 +1256,12 @@ snp_status decompress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uin
             u32* f_skip = f_out_cap + nf;
             u32* f_out_len = f_skip + nf;
             i32* f_status = reinterpret_cast<i32*>(f_out_len + nf);
-            ok = c->check(snp_launch_tag_index(static_cast<const u8*>(c->in.p), static_cast<u32>(n), hb, expected,
-                                               static_cast<u64*>(c->work.p), f_in_off, f_in_len, f_out_off, f_out_cap, f_skip, s),
-                          "tag index");
+            ok = indexed ? c->check(snp_launch_tag_index_finish(static_cast<const u8*>(c->in.p), static_cast<u32>(n), hb, expected,
+                                                                static_cast<u64*>(c->work.p), f_in_off, f_in_len, f_out_off, f_out_cap, f_skip, s),
+                                    "tag index")
+                         : c->check(snp_launch_tag_index(static_cast<const u8*>(c->in.p), static_cast<u32>(n), hb, expected,
+                                                         static_cast<u64*>(c->work.p), f_in_off, f_in_len, f_out_off, f_out_cap, f_skip, s),
+                                    "tag index");
             ok = ok && c->check(snp_launch_decompress(static_cast<const u8*>(c->in.p), f_in_off, f_in_len, nf,
                                                       static_cast<u8*>(c->out.p), f_out_off, f_out_cap, f_out_len, f_status,
                                                       nullptr, c->fenced | ((c->dec_lds / 256) << 8), s, f_skip),

@@ -392,27 +392,79 @@ extern "C" size_t snp_tag_index_workspace_bytes(u32 n, u32 hb)
 
 extern "C" size_t snp_tag_index_fallback_offset(u32 n, u32 hb) { return 2 * ws_entries(snp_tag_index_entries(n, hb)) + 8; }   // (ctl[2])
 
-// The workspace holds snp_tag_index_workspace_bytes(n, hb) bytes; its first snp_tag_index_entries words are the entry table when *fallback == 0
-// (the debug dump in capi.hip reads those).
+// The workspace holds snp_tag_index_workspace_bytes(n, hb) bytes; its first snp_tag_index_entries words are the entry table when the fallback flag is 0
+// (the debug dump in capi.hip reads those).  Three steps, so that a caller who uploads the stream in slices can index what has arrived:
+//   snp_launch_tag_index_begin   zeroes the control words;
+//   snp_launch_tag_index_chunks  k_tag_cand for chunks [first, first + count), IN ORDER (the tickets number the chunks across launches); chunk k
+//                                needs stream bytes [hb + k * 16 KiB, hb + (k + 1) * 16 KiB + 8) on the device (snp_tag_index_chunks_ready);
+//   snp_launch_tag_index_finish  the scan, the look-back fallback, the fragment table.
+namespace {
+struct TagIndexLayout {
+    u32 nent, nchunks;
+    u64 *scanned, *looked_back;
+    u32* ctl;                                                            // [0] k_tag_cand's ticket, [1] k_tag_index's, [2] the fallback flag
+    CandHandoff* hand;
+    CandTable* tables;
+};
+TagIndexLayout tag_index_layout(u64* work, u32 n, u32 hb)
+{
+    TagIndexLayout L;
+    L.nent = snp_tag_index_entries(n, hb);
+    L.nchunks = (L.nent - 1) / kSubs;
+    u8* const w = reinterpret_cast<u8*>(work);
+    L.scanned = work;
+    L.looked_back = reinterpret_cast<u64*>(w + ws_entries(L.nent));
+    L.ctl = reinterpret_cast<u32*>(w + 2 * ws_entries(L.nent));
+    L.hand = reinterpret_cast<CandHandoff*>(L.ctl + 16);
+    L.tables = reinterpret_cast<CandTable*>(reinterpret_cast<u8*>(L.hand) + (static_cast<size_t>(L.nchunks) + 2) * sizeof(CandHandoff));
+    return L;
+}
+}  // namespace
+
+// How many chunks of the stream are complete on the device once its first `uploaded` bytes are (of n).
+extern "C" u32 snp_tag_index_chunks_ready(u32 n, u32 hb, u64 uploaded)
+{
+    const u32 nchunks = (snp_tag_index_entries(n, hb) - 1) / kSubs;
+    if (uploaded >= n) return nchunks;
+    if (uploaded < static_cast<u64>(hb) + 8) return 0;
+    const u64 k = (uploaded - hb - 8) / kChunk;
+    return k < nchunks ? static_cast<u32>(k) : nchunks;
+}
+
+extern "C" hipError_t snp_launch_tag_index_begin(u64* work, u32 n, u32 hb, hipStream_t stream)
+{
+    const TagIndexLayout L = tag_index_layout(work, n, hb);
+    // (the candidate tables are written before they are read: only what precedes them needs zeroing)
+    return hipMemsetAsync(work, 0, reinterpret_cast<u8*>(L.tables) - reinterpret_cast<u8*>(work), stream);
+}
+
+extern "C" hipError_t snp_launch_tag_index_chunks(const u8* src, u32 n, u32 hb, u64* work, u32 first, u32 count, hipStream_t stream)
+{
+    (void)first;                                                         // (in order: the ticket counter IS the chunk number)
+    if (count == 0) return hipSuccess;
+    const TagIndexLayout L = tag_index_layout(work, n, hb);
+    hipLaunchKernelGGL(k_tag_cand, dim3(count), dim3(kThreads), 0, stream, src, n, hb, L.nchunks, L.tables, L.hand, L.ctl);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t snp_launch_tag_index_finish(const u8* src, u32 n, u32 hb, u32 expected, u64* work, u64* in_off, u32* in_len,
+                                                  u64* out_off, u32* out_cap, u32* skip, hipStream_t stream)
+{
+    const TagIndexLayout L = tag_index_layout(work, n, hb);
+    const u32 nfrag = (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
+    hipLaunchKernelGGL(k_tag_scan, dim3(1), dim3(kThreads), 0, stream, L.tables, n, hb, L.nchunks, L.scanned, L.ctl + 2);
+    hipLaunchKernelGGL(k_tag_index, dim3(L.nchunks), dim3(kThreads), 0, stream, src, n, hb, L.nchunks, L.looked_back, L.ctl + 1, L.ctl + 2);
+    hipLaunchKernelGGL(k_fragment_starts, dim3((nfrag + 255) / 256), dim3(256), 0, stream, L.scanned, L.looked_back, L.ctl + 2, L.nent, n, expected,
+                       nfrag, in_off, in_len, out_off, out_cap, skip);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t snp_launch_tag_index(const u8* src, u32 n, u32 hb, u32 expected, u64* work, u64* in_off, u32* in_len,
                                            u64* out_off, u32* out_cap, u32* skip, hipStream_t stream)
 {
-    const u32 nent = snp_tag_index_entries(n, hb);
-    const u32 nchunks = (nent - 1) / kSubs;
-    const u32 nfrag = (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
-    u8* const w = reinterpret_cast<u8*>(work);
-    u64* const scanned = work;
-    u64* const looked_back = reinterpret_cast<u64*>(w + ws_entries(nent));
-    u32* const ctl = reinterpret_cast<u32*>(w + 2 * ws_entries(nent));      // [0] k_tag_cand's ticket, [1] k_tag_index's, [2] the fallback flag
-    CandHandoff* const hand = reinterpret_cast<CandHandoff*>(ctl + 16);
-    CandTable* const tables = reinterpret_cast<CandTable*>(reinterpret_cast<u8*>(hand) + (static_cast<size_t>(nchunks) + 2) * sizeof(CandHandoff));
-    // (the candidate tables are written before they are read: only what precedes them needs zeroing)
-    hipError_t e = hipMemsetAsync(work, 0, reinterpret_cast<u8*>(tables) - w, stream);
+    hipError_t e = snp_launch_tag_index_begin(work, n, hb, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_tag_cand, dim3(nchunks), dim3(kThreads), 0, stream, src, n, hb, nchunks, tables, hand, ctl);
-    hipLaunchKernelGGL(k_tag_scan, dim3(1), dim3(kThreads), 0, stream, tables, n, hb, nchunks, scanned, ctl + 2);
-    hipLaunchKernelGGL(k_tag_index, dim3(nchunks), dim3(kThreads), 0, stream, src, n, hb, nchunks, looked_back, ctl + 1, ctl + 2);
-    hipLaunchKernelGGL(k_fragment_starts, dim3((nfrag + 255) / 256), dim3(256), 0, stream, scanned, looked_back, ctl + 2, nent, n, expected, nfrag,
-                       in_off, in_len, out_off, out_cap, skip);
-    return hipGetLastError();
+    e = snp_launch_tag_index_chunks(src, n, hb, work, 0, (snp_tag_index_entries(n, hb) - 1) / kSubs, stream);
+    if (e != hipSuccess) return e;
+    return snp_launch_tag_index_finish(src, n, hb, expected, work, in_off, in_len, out_off, out_cap, skip, stream);
 }

@@ -63,7 +63,7 @@ def ctx(request, monkeypatch):
     return c
 
 
-@pytest.mark.parametrize("size", [1, 14, 65536, 65537, 131072, 262144, 262145, 1000000, 4 << 20])
+@pytest.mark.parametrize("size", [1, 14, 65536, 65537, 131072, 262144, 262145, 1000000, 4 << 20, 40 << 20])   # (40 MiB: the stream goes up in slices, indexed as it lands)
 @pytest.mark.parametrize("kind", ["corpus", "low_entropy", "random"])
 def test_big_block_roundtrip_matches_oracle(ctx, kind, size):
     if kind == "corpus":
