@@ -27,7 +27,8 @@ size_t snp_tag_index_workspace_bytes(u32, u32);
 size_t snp_tag_index_fallback_offset(u32, u32);
 hipError_t snp_launch_tag_index(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
 u32 snp_tag_index_chunks_ready(u32, u32, u64);
-hipError_t snp_launch_tag_index_begin(u64*, u32, u32, hipStream_t);
+hipError_t snp_launch_tag_index_begin(u64*, u32, u32, int, hipStream_t);
+int snp_tag_index_look_back_only(u32, u32);
 hipError_t snp_launch_tag_index_chunks(const u8*, u32, u32, u64*, u32, u32, hipStream_t);
 hipError_t snp_launch_tag_index_finish(const u8*, u32, u32, u32, u64*, u64*, u32*, u64*, u32*, u32*, hipStream_t);
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
@@ -1225,10 +1226,10 @@ snp_status decompress_spans(snp_ctx* c, const HostSpans& in_spans, size_t n, uin
     // The upload.  One large stream from one host buffer goes up in slices on the copy stream, and the tag index's per-chunk pass (most of its
     // time, and independent chunk by chunk) runs on each slice as it lands.
     bool indexed = false;
-    if (ok && n && large && in_spans.count == 1 && n >= (8u << 20) && c->copy_stream_ready()) {
+    if (ok && n && large && in_spans.count == 1 && n >= (8u << 20) && !snp_tag_index_look_back_only(static_cast<u32>(n), expected) && c->copy_stream_ready()) {
         const u8* const host_in = in_spans.ptr[0];
         const size_t slice = n / 8 > (4u << 20) ? (n / 8 + 4095) / 4096 * 4096 : (4u << 20);
-        ok = c->check(snp_launch_tag_index_begin(static_cast<u64*>(c->work.p), static_cast<u32>(n), hb, s), "tag index") &&
+        ok = c->check(snp_launch_tag_index_begin(static_cast<u64*>(c->work.p), static_cast<u32>(n), hb, 0, s), "tag index") &&
              c->check(hipEventRecord(c->copy_ev[0], s), "event") && c->check(hipStreamWaitEvent(c->copy_stream, c->copy_ev[0], 0), "wait");
         u32 done_chunks = 0, k = 0;
         for (size_t off = 0; off < n && ok; off += slice, ++k) {

@@ -283,6 +283,7 @@ __global__ __launch_bounds__(kThreads) void k_tag_scan(const CandTable* __restri
     __shared__ u32 s_row[kThreads];
     __shared__ u64 s_op[kThreads];
     __shared__ u32 s_fail;
+    if (__hip_atomic_load(fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (the caller asked for the look-back pass)
     const u32 per = (nchunks + kThreads - 1) / kThreads;
     const u32 k0 = min(threadIdx.x * per, nchunks), k1 = min(k0 + per, nchunks);
     if (threadIdx.x == 0) s_fail = 0;
@@ -431,11 +432,15 @@ extern "C" u32 snp_tag_index_chunks_ready(u32 n, u32 hb, u64 uploaded)
     return k < nchunks ? static_cast<u32>(k) : nchunks;
 }
 
-extern "C" hipError_t snp_launch_tag_index_begin(u64* work, u32 n, u32 hb, hipStream_t stream)
+// look_back_only: skip the candidate pass (snp_launch_tag_index_chunks / the scan do nothing) -- for streams that are mostly literals longer than a
+// chunk (hardly compressed data), where the candidate pass would fail anyway and only add its 4.7 ms per GiB.
+extern "C" hipError_t snp_launch_tag_index_begin(u64* work, u32 n, u32 hb, int look_back_only, hipStream_t stream)
 {
     const TagIndexLayout L = tag_index_layout(work, n, hb);
     // (the candidate tables are written before they are read: only what precedes them needs zeroing)
-    return hipMemsetAsync(work, 0, reinterpret_cast<u8*>(L.tables) - reinterpret_cast<u8*>(work), stream);
+    hipError_t e = hipMemsetAsync(work, 0, reinterpret_cast<u8*>(L.tables) - reinterpret_cast<u8*>(work), stream);
+    if (e == hipSuccess && look_back_only) e = hipMemsetAsync(L.ctl + 2, 1, 4, stream);   // (any non-zero value is "wanted")
+    return e;
 }
 
 extern "C" hipError_t snp_launch_tag_index_chunks(const u8* src, u32 n, u32 hb, u64* work, u32 first, u32 count, hipStream_t stream)
@@ -459,12 +464,15 @@ extern "C" hipError_t snp_launch_tag_index_finish(const u8* src, u32 n, u32 hb, 
     return hipGetLastError();
 }
 
+extern "C" int snp_tag_index_look_back_only(u32 n, u32 expected) { return static_cast<u64>(n) * 100 >= static_cast<u64>(expected) * 85; }
+
 extern "C" hipError_t snp_launch_tag_index(const u8* src, u32 n, u32 hb, u32 expected, u64* work, u64* in_off, u32* in_len,
                                            u64* out_off, u32* out_cap, u32* skip, hipStream_t stream)
 {
-    hipError_t e = snp_launch_tag_index_begin(work, n, hb, stream);
+    const int lbo = snp_tag_index_look_back_only(n, expected);
+    hipError_t e = snp_launch_tag_index_begin(work, n, hb, lbo, stream);
     if (e != hipSuccess) return e;
-    e = snp_launch_tag_index_chunks(src, n, hb, work, 0, (snp_tag_index_entries(n, hb) - 1) / kSubs, stream);
+    if (!lbo) e = snp_launch_tag_index_chunks(src, n, hb, work, 0, (snp_tag_index_entries(n, hb) - 1) / kSubs, stream);
     if (e != hipSuccess) return e;
     return snp_launch_tag_index_finish(src, n, hb, expected, work, in_off, in_len, out_off, out_cap, skip, stream);
 }
