@@ -87,8 +87,8 @@ snp_status snp_ctx_synchronize(snp_ctx* ctx);
  *        2 = microseconds the chosen hash-table workspace took in the placement probe (512 table-walk probes per fragment; 0: no search ran),
  *        3 = candidate pieces the workspace search allocated,
  *        4 = microseconds the whole search took (wall clock),  5 = most bytes it held at once (every candidate coexists until it ends),
- *        6 = large single blocks whose tag index needed the look-back pass (a chunk entry that was no candidate: literals longer than 16 KiB of
- *            stream -- incompressible data -- or an irregular stream; tag_index.hip). */
+ *        6 = large single blocks whose tag index took the look-back pass (hardly compressed or irregular streams, or more incompressible regions
+ *            than it pays to resolve one by one; tag_index.hip). */
 uint64_t snp_ctx_counter(const snp_ctx* ctx, int which);
 
 /* Per-context configuration.  A library loaded into a long-running service is configured through these, per context and at any

@@ -20,9 +20,13 @@
 //       have merged, and their (usually one) landing point in chunk k + 1 is a CANDIDATE entry of that chunk, handed to the neighbour only (no
 //       chain: every workgroup publishes before it waits).  For each of its own <= 8 candidates it records what step 2 would have recorded:
 //       the sub-chunk entry points and the exit, output bytes counted from the entry.
-//   2b. k_tag_scan: ONE workgroup walks the candidate tables in stream order (64 chunks' tables staged in LDS at a time): the true entry of
-//       chunk k selects a row, the row gives the entry of chunk k + 1.  An entry that is no candidate (a long literal that lands in the middle
-//       of a chunk and has not merged, more than 8 distinct landings) raises a flag, and the look-back kernel of step 2 runs after all.
+//   2b. k_tag_scan: ONE workgroup.  A chunk is a function  row -> (row of the next chunk | a position further on | end, output bytes); functions
+//       compose: every thread evaluates its run of chunks for each row, thread 0 chains the runs, every thread replays its run and writes the entries.
+//   2c. k_tag_fix: a landing that is no candidate (a literal longer than a chunk -- incompressible fragments -- lands in the middle of a chunk whose
+//       own walks started in its body) stops the scan; one workgroup follows the true chain from there, giving each landing its row (from the tag's
+//       own bytes when it leaves its chunk by itself, from the chunk's table otherwise) until the chain is on a candidate again; the scan runs
+//       again (its run functions are cached: only runs that stopped at the landing are evaluated anew).  Same kernel, same workgroup, one pass per
+//       incompressible region; on anything irregular, or when the passes would cost more than it (one per 417 chunks), the look-back kernel runs.
 // The entry table (one entry per 4 KiB of compressed data) is searched per fragment by k_fragment_starts; the
 // fragment decoder (k_decompress<.., FRAG = true>) then parses at most 4 KiB of tags before its fragment begins.
 // Anything that is not a well-formed stream ending exactly at (n, declared length) marks the table irregular and the
@@ -175,7 +179,9 @@ struct CandTable {                                // what step 2 would record fo
     u32 nxt[kMaxCand];                            // which candidate of the NEXT chunk that entry is (its row there), kDone, or kFail
 };
 constexpr u32 kDone = kMaxCand;                   // the stream ended (entry = (n, op) from here on)
-constexpr u32 kFail = kMaxCand + 1;               // not a candidate of the next chunk, irregular, or it jumps over the next chunk: the look-back kernel runs
+constexpr u32 kFail = kMaxCand + 1;               // irregular from here on: the look-back kernel runs (and marks the table irregular)
+constexpr u32 kByPos = kMaxCand + 2;              // the next entry is the POSITION ip[c][kSubs - 1]: a landing beyond the next chunk, or in it but not
+                                                  // among its candidates -- the scan looks the position up when it gets there (k_tag_fix adds the row)
 struct CandHandoff {                              // chunk k - 1 -> chunk k: the candidates, then the flag (release / acquire)
     u32 ready;
     u32 ncand;
@@ -263,85 +269,253 @@ __global__ __launch_bounds__(kThreads) void k_tag_cand(const u8* __restrict__ sr
             t->op[threadIdx.x][sc - 1] = rop[sc];
         }
         const u32 out = rip[kSubs];
-        u32 nx = kFail;
-        if (out == n) nx = kDone;
-        else if (out != kBadIp && s_next_ncand != kWide)
+        u32 nx = out == kBadIp ? kFail : out == n ? kDone : kByPos;
+        if (nx == kByPos && s_next_ncand != kWide)
             for (u32 c = 0; c < kMaxCand; ++c)
                 if (c < s_next_ncand && s_next_key[c] == out) nx = c;
         t->nxt[threadIdx.x] = nx;
     }
 }
 
-// One workgroup: the true entries out of the candidate tables.  A chunk is a function  row -> (row of the next chunk, output bytes)  on at most
-// 8 rows (+ two absorbing states); functions compose, so: every thread composes its run of chunks for all 8 rows, thread 0 chains the kThreads
-// run functions, every thread replays its run from its true row and writes the entries.
-__global__ __launch_bounds__(kThreads) void k_tag_scan(const CandTable* __restrict__ tables, u32 n, u32 hb, u32 nchunks, u64* __restrict__ entries,
-                                                      u32* __restrict__ fallback)
+// ---- step 2b: the scan --------------------------------------------------------------------------------------------------------------------
+// The state between two chunks: a ROW of the next chunk's table, a POSITION further on (looked up when its chunk comes), the END of the
+// stream, FAILED (irregular), or PENDING (a position that is no candidate: k_tag_fix adds its row, the scan runs again).
+enum : u32 { kStRow = 0, kStPos = 1, kStEnd = 2, kStFail = 3, kStPend = 4 };
+struct ScanState {
+    u32 kind, v;                                  // v: row (kStRow) or stream position (kStPos)
+    u64 op;                                       // output bytes before the entry
+};
+struct ScanCtl {                                  // in the workspace's control words
+    u32 cand_ticket, look_back_ticket, fallback;  // (fallback: the look-back kernel is wanted)
+    u32 complete;                                 // the scan reached the end of the stream: the entries are final
+    u32 pending, pend_chunk, pend_ip, pend_op;    // a landing that needs a row (k_tag_fix)
+    u32 cached;                                   // the run functions of the first pass are in the workspace (k_tag_fix only ADDS rows: they stay valid,
+};                                                //  except where a run stopped at a pending landing)
+struct RunCache {                                 // [thread][row]
+    u8 kind[kThreads][kMaxCand];
+    u32 v[kThreads][kMaxCand];
+    u64 op[kThreads][kMaxCand];
+};
+
+// One chunk.  entries != nullptr: the replay -- writes the chunk's entries and files the pending request.
+__device__ __forceinline__ void scan_step(ScanState& s, const u32 k, const CandTable* __restrict__ tables, const u32 n, const u32 hb,
+                                          u64* __restrict__ entries, ScanCtl* __restrict__ ctl)
 {
-    __shared__ u8 s_nxt[kThreads][kMaxCand];
-    __shared__ u64 s_sum[kThreads][kMaxCand];
-    __shared__ u32 s_row[kThreads];
-    __shared__ u64 s_op[kThreads];
-    __shared__ u32 s_fail;
-    if (__hip_atomic_load(fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (the caller asked for the look-back pass)
+    if (s.kind == kStFail || s.kind == kStPend) return;
+    if (s.op > 0x7fffffffull) { s.kind = kStFail; return; }
+    u64* const e = entries ? entries + static_cast<u64>(k) * kSubs : nullptr;
+    const u32 op = static_cast<u32>(s.op);
+    if (s.kind == kStEnd) {
+        if (e) for (u32 sc = 0; sc < kSubs; ++sc) e[sc] = kValid | pack(op, n);
+        return;
+    }
+    const u64 end = hb + static_cast<u64>(k + 1) * kChunk;
+    const CandTable& t = tables[k];
+    if (s.kind == kStPos) {
+        if (s.v >= end) {                                                // a literal jumps over this chunk
+            if (e) for (u32 sc = 0; sc < kSubs; ++sc) e[sc] = kValid | pack(op, s.v);
+            return;
+        }
+        u32 row = kMaxCand;
+        if (t.ncand != kWide)
+            for (u32 c = 0; c < kMaxCand; ++c)
+                if (c < t.ncand && t.key[c] == s.v) row = c;
+        if (row == kMaxCand) {
+            if (ctl) { ctl->pend_chunk = k; ctl->pend_ip = s.v; ctl->pend_op = op; ctl->pending = 1; }
+            s.kind = kStPend;
+            return;
+        }
+        s.kind = kStRow;
+        s.v = row;
+    }
+    if (t.ncand == kWide || s.v >= t.ncand) { s.kind = kStFail; return; }   // (cannot happen: a row comes from nxt or from the lookup above)
+    const u32 row = s.v;
+    if (e) e[0] = kValid | pack(op, t.key[row]);
+    for (u32 sc = 1; sc < kSubs; ++sc) {
+        const u64 sum = s.op + t.op[row][sc - 1];
+        if (t.ip[row][sc - 1] == kBadIp || sum > 0x7fffffffull) { s.kind = kStFail; return; }
+        if (e) e[sc] = kValid | pack(static_cast<u32>(sum), t.ip[row][sc - 1]);
+    }
+    s.op += t.op[row][kSubs - 1];
+    const u32 nx = t.nxt[row];
+    if (nx < kMaxCand) { s.kind = kStRow; s.v = nx; }
+    else if (nx == kDone) s.kind = kStEnd;
+    else if (nx == kByPos) { s.kind = kStPos; s.v = t.ip[row][kSubs - 1]; }
+    else s.kind = kStFail;
+}
+
+// One workgroup.  A run of chunks is a function on <= 8 rows: every thread evaluates its run for each row; thread 0 chains the runs (a run entered
+// by POSITION is evaluated then and there: chunks a literal jumps over cost no memory access); every thread replays its run from its true
+// entry state, writing the entries.  `last`: no k_tag_fix follows -- a pending landing means the look-back kernel.
+struct ScanLds {                                  // (carved out of the workgroup's LDS pool: the table of k_tag_fix lives there between scans)
+    u8 r_kind[kThreads][kMaxCand];
+    u32 r_v[kThreads][kMaxCand];
+    u64 r_op[kThreads][kMaxCand];
+    u8 in_kind[kThreads];
+    u32 in_v[kThreads];
+    u64 in_op[kThreads];
+};
+__device__ __forceinline__ void scan_pass(const CandTable* __restrict__ tables, u32 n, u32 hb, u32 nchunks, u64* __restrict__ entries,
+                                          ScanCtl* __restrict__ ctl, RunCache* __restrict__ cache, const bool last, ScanLds& L, u32& s_final)
+{
+    auto& r_kind = L.r_kind;
+    auto& r_v = L.r_v;
+    auto& r_op = L.r_op;
+    auto& in_kind = L.in_kind;
+    auto& in_v = L.in_v;
+    auto& in_op = L.in_op;
     const u32 per = (nchunks + kThreads - 1) / kThreads;
     const u32 k0 = min(threadIdx.x * per, nchunks), k1 = min(k0 + per, nchunks);
-    if (threadIdx.x == 0) s_fail = 0;
+    const bool cached = __hip_atomic_load(&ctl->cached, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     for (u32 r = 0; r < kMaxCand; ++r) {
-        u32 row = r;
-        u64 sum = 0;
-        for (u32 k = k0; k < k1 && row < kMaxCand; ++k) {
-            const CandTable& t = tables[k];
-            if (t.ncand == kWide || row >= t.ncand) { row = kFail; break; }
-            sum += t.op[row][kSubs - 1];
-            row = t.nxt[row];
+        ScanState s{kStRow, r, 0};
+        if (cached && cache->kind[threadIdx.x][r] != kStPend) {          // (a later pass: only what stopped at a pending landing is evaluated again)
+            s.kind = cache->kind[threadIdx.x][r];
+            s.v = cache->v[threadIdx.x][r];
+            s.op = cache->op[threadIdx.x][r];
+        } else {
+            if (k0 < k1 && (tables[k0].ncand == kWide || r >= tables[k0].ncand)) s.kind = kStFail;   // (no such row: never selected)
+            for (u32 k = k0; k < k1 && s.kind != kStFail && s.kind != kStPend; ++k) scan_step(s, k, tables, n, hb, nullptr, nullptr);
+            cache->kind[threadIdx.x][r] = static_cast<u8>(s.kind);
+            cache->v[threadIdx.x][r] = s.v;
+            cache->op[threadIdx.x][r] = s.op;
         }
-        s_nxt[threadIdx.x][r] = static_cast<u8>(row);
-        s_sum[threadIdx.x][r] = sum;
+        r_kind[threadIdx.x][r] = static_cast<u8>(s.kind);
+        r_v[threadIdx.x][r] = s.v;
+        r_op[threadIdx.x][r] = s.op;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        u32 row = 0;                                                     // chunk 0 has one candidate: the first tag after the preamble
-        u64 op = 0;
+        ScanState s{kStRow, 0, 0};                                       // chunk 0 has one candidate: the first tag after the preamble
         for (u32 t = 0; t < kThreads; ++t) {
-            s_row[t] = row;
-            s_op[t] = op;
-            if (row < kMaxCand) {
-                op += s_sum[t][row];
-                row = s_nxt[t][row];
+            in_kind[t] = static_cast<u8>(s.kind);
+            in_v[t] = s.v;
+            in_op[t] = s.op;
+            const u32 a0 = min(t * per, nchunks), a1 = min(a0 + per, nchunks);
+            if (s.kind == kStRow && a0 < a1) {
+                const u32 r = s.v;
+                s.kind = r_kind[t][r];
+                s.v = r_v[t][r];
+                s.op += r_op[t][r];
+            } else if (s.kind == kStPos) {
+                for (u32 k = a0; k < a1; ++k) scan_step(s, k, tables, n, hb, nullptr, nullptr);
             }
         }
+        s_final = s.kind;
     }
     __syncthreads();
-    u32 row = s_row[threadIdx.x];
-    u64 op = s_op[threadIdx.x];
-    bool fail = false;
-    for (u32 k = k0; k < k1; ++k) {
-        u64* const e = entries + static_cast<u64>(k) * kSubs;
-        if (row == kFail || op > 0x7fffffffull) { fail = true; break; }
-        if (row == kDone) {
-            for (u32 sc = 0; sc < kSubs; ++sc) e[sc] = kValid | pack(static_cast<u32>(op), n);
-            continue;
-        }
-        const CandTable& t = tables[k];
-        if (t.ncand == kWide || row >= t.ncand) { fail = true; break; }
-        e[0] = kValid | pack(static_cast<u32>(op), t.key[row]);
-        bool bad = false;
-        for (u32 sc = 1; sc < kSubs; ++sc) {
-            bad = bad || t.ip[row][sc - 1] == kBadIp || op + t.op[row][sc - 1] > 0x7fffffffull;
-            e[sc] = kValid | pack(static_cast<u32>(op + t.op[row][sc - 1]), t.ip[row][sc - 1]);
-        }
-        if (bad) { fail = true; break; }
-        op += t.op[row][kSubs - 1];
-        row = t.nxt[row];
+    ScanState s{in_kind[threadIdx.x], in_v[threadIdx.x], in_op[threadIdx.x]};
+    for (u32 k = k0; k < k1; ++k) scan_step(s, k, tables, n, hb, entries, ctl);
+    if (k0 < k1 && k1 == nchunks && s.kind == kStEnd) entries[static_cast<u64>(nchunks) * kSubs] = kValid | pack(static_cast<u32>(s.op), n);
+    if (threadIdx.x == 0) {
+        ctl->cached = 1;
+        if (s_final == kStEnd) ctl->complete = 1;
+        else if (s_final != kStPend || last) ctl->fallback = 1;          // irregular (or the stream does not end with its last chunk); or out of passes
     }
-    if (k1 == nchunks && k0 < k1 && !fail) {                            // (the thread that owns the last chunk: the entry after it)
-        if (row == kDone) entries[static_cast<u64>(nchunks) * kSubs] = kValid | pack(static_cast<u32>(op), n);
-        else fail = true;                                                // the stream does not end with its last chunk: irregular
-    }
-    if (fail) atomicOr(&s_fail, 1u);
     __syncthreads();
-    if (threadIdx.x == 0 && s_fail) *fallback = 1;
+}
+
+// ---- step 2c: a landing that was no candidate gets its row ---------------------------------------------------------------------------------------
+// One workgroup follows the true chain from the pending landing: a tag that leaves its chunk by itself (a literal longer than what is left of the
+// chunk: the incompressible fragments) gets its row from its own bytes; anything else from the chunk's table, built here; until the chain lands on
+// a candidate again (it has merged with the walks the candidates came from) or the budget of this pass is spent.
+constexpr u32 kFixBudget = 4096;                  // landings one pass may give a row
+constexpr u32 kFixPasses = 512;                   // passes at most (each ends where the chain rejoins the candidates: one per incompressible region)
+constexpr u32 kChunksPerPass = 417;               // a pass costs ~0.35 ms, the look-back kernel 0.84 us per chunk: more passes than chunks / 417 and it is cheaper
+struct FixLds {
+    u64 T[kChunk];
+    __attribute__((aligned(16))) u8 raw[kChunk + 16];
+};
+struct FixVars { u32 k, ip, go, far, next, len; };
+__device__ __forceinline__ void fix_pass(const u8* __restrict__ src, u32 n, u32 hb, CandTable* __restrict__ tables, ScanCtl* __restrict__ ctl,
+                                         FixLds& F, FixVars& V)
+{
+    u64* const T = F.T;
+    u8* const s_raw = F.raw;
+    u32 &s_k = V.k, &s_ip = V.ip, &s_go = V.go, &s_far = V.far, &s_next = V.next, &s_len = V.len;
+    if (threadIdx.x == 0) { s_k = ctl->pend_chunk; s_ip = ctl->pend_ip; s_go = 1; }
+    __syncthreads();
+    for (u32 it = 0; it < kFixBudget; ++it) {
+        if (!s_go) break;
+        const u32 k = s_k, ip = s_ip;
+        const u64 base = hb + static_cast<u64>(k) * kChunk, end = base + kChunk;
+        // the tag at ip, from its own bytes: does it leave the chunk by itself?
+        if (threadIdx.x == 0) {
+            u64 q = 0;
+            for (u32 i = 0; i < 8 && ip + i < n; ++i) q |= static_cast<u64>(src[ip + i]) << (8 * i);
+            const u32 c = static_cast<u32>(q) & 0xffu, type = c & 3u, hi6 = c >> 2;
+            const u32 extra = type == 0 ? (hi6 >= 60 ? hi6 - 59 : 0) : (type == 3 ? 4 : type);
+            const u32 b1234 = static_cast<u32>(q >> 8);
+            const u32 trailer = extra >= 4 ? b1234 : (b1234 & ((1u << (8 * extra)) - 1u));
+            const u64 len = type == 0 ? (hi6 >= 60 ? static_cast<u64>(trailer) + 1 : hi6 + 1) : 0;
+            const u64 next = static_cast<u64>(ip) + 1 + extra + len;
+            s_far = type == 0 && static_cast<u64>(ip) + 1 + extra <= n && next >= end && next <= n && len <= 0x7fffffffull;
+            s_next = static_cast<u32>(next);
+            s_len = static_cast<u32>(len);
+        }
+        __syncthreads();
+        u32 rip[kSubs + 1], rop[kSubs + 1];
+        if (s_far) {                                                     // walk_chunk's record for a single tag that leaves the chunk
+            for (u32 sc = 0; sc <= kSubs; ++sc) {
+                const bool after = sc == kSubs || base + static_cast<u64>(sc) * kSub > ip;
+                rip[sc] = after ? s_next : ip;
+                rop[sc] = after ? s_len : 0u;
+            }
+        } else {
+            build_table(T, s_raw, src, n, base);
+            walk_chunk(T, n, base, ip, 0u, rip, rop);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            CandTable& t = tables[k];
+            u32 r = t.ncand == kWide ? 0u : t.ncand;
+            if (r >= kMaxCand) {
+                ctl->fallback = 1;                                       // no room for another row
+                s_go = 0;
+            } else {
+                t.key[r] = ip;
+                for (u32 sc = 1; sc <= kSubs; ++sc) {
+                    t.ip[r][sc - 1] = rip[sc];
+                    t.op[r][sc - 1] = rop[sc];
+                }
+                const u32 out = rip[kSubs];
+                u32 nx = out == kBadIp ? kFail : out == n ? kDone : kByPos;
+                bool joined = nx != kByPos;                              // (the end, or irregular: nothing more to add)
+                u32 ko = 0;
+                if (nx == kByPos) {
+                    ko = static_cast<u32>((out - hb) / kChunk);
+                    const CandTable& o = tables[ko];
+                    if (o.ncand != kWide)
+                        for (u32 c = 0; c < kMaxCand; ++c)
+                            if (c < o.ncand && o.key[c] == out) { joined = true; if (ko == k + 1) nx = c; }
+                }
+                t.nxt[r] = nx;
+                t.ncand = r + 1;
+                if (joined) s_go = 0;
+                else { s_k = ko; s_ip = out; }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ctl->pending = 0;
+    __syncthreads();
+}
+
+// One workgroup: scan; while a landing is pending: give it (and what follows it, up to the rejoin) rows, scan again.
+__global__ __launch_bounds__(kThreads) void k_tag_scan(const u8* __restrict__ src, CandTable* __restrict__ tables, u32 n, u32 hb, u32 nchunks,
+                                                      u64* __restrict__ entries, ScanCtl* __restrict__ ctl, RunCache* __restrict__ cache)
+{
+    __shared__ __attribute__((aligned(16))) u8 pool[sizeof(FixLds) > sizeof(ScanLds) ? sizeof(FixLds) : sizeof(ScanLds)];
+    __shared__ FixVars vars;
+    __shared__ u32 s_final, s_more;
+    if (__hip_atomic_load(&ctl->fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (the caller asked for the look-back pass)
+    for (u32 pass = 0;; ++pass) {
+        scan_pass(tables, n, hb, nchunks, entries, ctl, cache, pass >= min(kFixPasses, max(1u, nchunks / kChunksPerPass)), *reinterpret_cast<ScanLds*>(pool), s_final);
+        if (threadIdx.x == 0) s_more = ctl->complete == 0 && ctl->fallback == 0 && ctl->pending != 0;
+        __syncthreads();
+        if (!s_more) break;
+        fix_pass(src, n, hb, tables, ctl, *reinterpret_cast<FixLds*>(pool), vars);
+    }
 }
 
 // One thread per output fragment: the last table entry at or before the fragment's first output byte.
@@ -388,7 +562,7 @@ extern "C" size_t snp_tag_index_workspace_bytes(u32 n, u32 hb)
 {
     const u32 nent = snp_tag_index_entries(n, hb);
     const u32 nchunks = (nent - 1) / kSubs;
-    return 2 * ws_entries(nent) + 64 + (static_cast<size_t>(nchunks) + 2) * sizeof(CandHandoff) + static_cast<size_t>(nchunks) * sizeof(CandTable) + 64;
+    return 2 * ws_entries(nent) + 64 + (static_cast<size_t>(nchunks) + 2) * sizeof(CandHandoff) + static_cast<size_t>(nchunks) * sizeof(CandTable) + 128 + sizeof(RunCache);
 }
 
 extern "C" size_t snp_tag_index_fallback_offset(u32 n, u32 hb) { return 2 * ws_entries(snp_tag_index_entries(n, hb)) + 8; }   // (ctl[2])
@@ -406,6 +580,7 @@ struct TagIndexLayout {
     u32* ctl;                                                            // [0] k_tag_cand's ticket, [1] k_tag_index's, [2] the fallback flag
     CandHandoff* hand;
     CandTable* tables;
+    RunCache* cache;
 };
 TagIndexLayout tag_index_layout(u64* work, u32 n, u32 hb)
 {
@@ -418,6 +593,7 @@ TagIndexLayout tag_index_layout(u64* work, u32 n, u32 hb)
     L.ctl = reinterpret_cast<u32*>(w + 2 * ws_entries(L.nent));
     L.hand = reinterpret_cast<CandHandoff*>(L.ctl + 16);
     L.tables = reinterpret_cast<CandTable*>(reinterpret_cast<u8*>(L.hand) + (static_cast<size_t>(L.nchunks) + 2) * sizeof(CandHandoff));
+    L.cache = reinterpret_cast<RunCache*>((reinterpret_cast<uintptr_t>(L.tables + L.nchunks) + 63) / 64 * 64);
     return L;
 }
 }  // namespace
@@ -457,7 +633,7 @@ extern "C" hipError_t snp_launch_tag_index_finish(const u8* src, u32 n, u32 hb, 
 {
     const TagIndexLayout L = tag_index_layout(work, n, hb);
     const u32 nfrag = (expected + SNP_BLOCK_SIZE - 1) / SNP_BLOCK_SIZE;
-    hipLaunchKernelGGL(k_tag_scan, dim3(1), dim3(kThreads), 0, stream, L.tables, n, hb, L.nchunks, L.scanned, L.ctl + 2);
+    hipLaunchKernelGGL(k_tag_scan, dim3(1), dim3(kThreads), 0, stream, src, L.tables, n, hb, L.nchunks, L.scanned, reinterpret_cast<ScanCtl*>(L.ctl), L.cache);
     hipLaunchKernelGGL(k_tag_index, dim3(L.nchunks), dim3(kThreads), 0, stream, src, n, hb, L.nchunks, L.looked_back, L.ctl + 1, L.ctl + 2);
     hipLaunchKernelGGL(k_fragment_starts, dim3((nfrag + 255) / 256), dim3(256), 0, stream, L.scanned, L.looked_back, L.ctl + 2, L.nent, n, expected,
                        nfrag, in_off, in_len, out_off, out_cap, skip);
