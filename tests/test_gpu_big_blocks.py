@@ -82,6 +82,8 @@ def test_big_block_roundtrip_matches_oracle(ctx, kind, size):
     # never need it; a literal longer than a 16 KiB chunk of the stream (incompressible fragments) jumps over the next chunk's candidates and does.
     if took_fragments and kind == "low_entropy" and size >= 65536:   # (a stream of >= 85 % of its output's size goes to the look-back pass unasked)
         assert ctx.counter(6) == 0
+    if took_fragments and kind == "corpus" and size == 1000000:       # one incompressible region (a jpeg): resolved by a pass of the scan's own
+        assert ctx.counter(6) == 0
     if took_fragments and kind == "random" and size >= 131072:       # (two literals of 64 KiB: the first lands four chunks on, short of the end)
         assert ctx.counter(6) == 1
 
