@@ -94,13 +94,37 @@ def build(kind, total=65536):
                 off = min(produced, (1, 3, 60, 64, 65, 70, 130, 131, 200)[(k + j) % 9])
                 emit(copy2(ln, off), ln)
             k += 1
+    elif kind == "two_slot_literals":           # literals of 64 .. 130 bytes -- one slot of a batch, two slots (65 .. 128), the whole wave (> 128) -- between
+        import random                           # runs of short tags of every length, so that the second slot falls on every lane incl. the 64th (it must then
+        rnd = random.Random(23)                 # wait for the next batch with its first), on the stage's limit, and -- the last literal -- on the block's end
+        emit(lit(bytes(range(90))), 90)
+        k = 0
+        lens = (64, 65, 66, 100, 127, 128, 129, 130, 96, 65, 128)
+        while produced + 400 <= total - 128:
+            n = lens[k % len(lens)]
+            emit(lit(bytes((3 * k + i) & 255 for i in range(n))), n)
+            for j in range((k * 7) % 67):
+                if j % 3:
+                    emit(copy2(1 + (k + j) % 9, min(produced, 1 + (5 * j + k) % 300)), 1 + (k + j) % 9)
+                else:
+                    emit(lit(bytes([rnd.randrange(256)])), 1)
+            if k % 5 == 0:                                                  # a long run of 64-byte copies: the stage fills up (2 KiB) in mid-batch
+                for j in range(40):
+                    emit(copy2(64, min(produced, 64 + j)), 64)
+            k += 1
+        tail = total - produced
+        if 65 <= tail <= 128:
+            emit(lit(bytes(tail)), tail)
+        else:
+            emit(lit(bytes(tail - 100)), tail - 100)
+            emit(lit(bytes(range(100))), 100)                               # a two-slot literal that ends with the block
     if produced < total:
         emit(lit(bytes(total - produced)), total - produced)
     return varint(total) + bytes(out)
 
 
 KINDS = ("copy4_len4_period5", "copy4_len64_period5", "literals_of_f4", "literals_of_ff_period61", "literals_of_14_period7",
-         "copy2_offsets_f4f4", "period7_mix", "edge_sweep", "long_literals_between_batches")
+         "copy2_offsets_f4f4", "period7_mix", "edge_sweep", "long_literals_between_batches", "two_slot_literals")
 
 
 def main():

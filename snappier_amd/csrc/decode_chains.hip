@@ -226,13 +226,13 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
         // What this trip does: builds the next super-window (nothing may be held then), or takes the next batch of the list.
         u32 mode = emitted == ntok ? kModeWindow : kModeBatch;
         // the new batch (kModeBatch): what outlives the held batch's finish
-        u32 len = 0, off = 0, drel = 0, ne = 0, incl = 0, body = 0, s_first = 0, s_len0 = 0, s_body0 = 0;
+        u32 len = 0, off = 0, drel = 0, ne = 0, incl = 0, body = 0, s_first = 0, s_len0 = 0, s_body0 = 0, taken = 0;
         bool is_lit = false, live = true;
         if (mode == kModeBatch) {
 SNP_MARK(B_top);
             // ---- one batch: the next <= 64 tags of the list ----
             const u32 t = emitted + lane;
-            const bool have = t < ntok;
+            bool have = t < ntok;
             const u32 pos = c_pos[have ? t : emitted];                  // (idle lanes re-read the batch's first position)
             // The tag bytes were requested a batch ago (q_pf); only the first batch of a super-window loads them here, and that load's wait
             // stays on ITS path: merged at a join, the compiler would drain vmcnt in EVERY batch.
@@ -257,6 +257,35 @@ SNP_MARK(B_top);
             len = (long_lit ? trailer : (hi6 & (type == 1 ? 7u : 63u))) + (type == 1 ? 4u : 1u);
             off = is_lit ? 0u : (type == 1 ? (((c >> 5) << 8) | (b1234 & 0xffu)) : trailer);
             body = pos + 1u + extra;                          // a literal's bytes, from wbase
+            // A literal of 65..128 bytes takes TWO slots of the batch -- its first 64 bytes, the rest -- instead of ending it (plain text and
+            // low-entropy data are full of them, and each one used to cost a drain of the held batch): the tags are dealt out to the lanes
+            // again through the LDS words that are idle between super-window builds.  `last`: the slot is the last (or only) one of its tag.
+            u64 last = ~0ull;
+            u32 len_tag0 = 0;
+            bool dealt = false;                                         // (wave-uniform: the slots were dealt out again)
+            if (!FRAG && __builtin_expect(ballot64((q & 0xc0ffu) == 0x40f0u) != 0ull, 0)) {   // (tag 0xf0, length byte 64..127: every compressor's form of such a literal;
+                                                                                           //  idle lanes repeat the batch's first tag: no need to mask them)
+                const bool two = have && is_lit && len > 64u && len <= 128u;
+                dealt = true;
+                len_tag0 = read_lane(len, 0);
+                const u32 cnt = have ? (two ? 2u : 1u) : 0u;
+                const u32 sincl = wave_inclusive_scan(cnt);
+                const u32 s0 = sincl - cnt;
+                const bool fits = have && sincl <= SNP_WAVE;               // (a prefix of the lanes: the tags this batch's 64 slots hold)
+                const u32 nslots = read_lane(sincl, static_cast<u32>(__builtin_popcountll(ballot64(fits))) - 1u);
+                // slot word: len (8; a literal > 128 bytes keeps 255: it ends the batch as before) | last (1) | literal (1) | body (16) | offset (32)
+                if (fits) c_busy[s0] = (two ? 64u : min(len, 255u)) | (two ? 0u : 0x100u) | (is_lit ? 0x200u : 0u) | (static_cast<u64>(body) << 10) | (static_cast<u64>(off) << 26);
+                if (fits && two) c_busy[s0 + 1u] = (len - 64u) | 0x100u | 0x200u | (static_cast<u64>(body + 64u) << 10);
+                lanes_sync_lds();
+                const u64 w = c_busy[lane];
+                lanes_sync_lds();
+                have = lane < nslots;
+                len = static_cast<u32>(w) & 0xffu;
+                is_lit = (w & 0x200u) != 0;
+                body = static_cast<u32>(w >> 10) & 0xffffu;
+                off = static_cast<u32>(w >> 26);
+                last = ballot64(have && (w & 0x100u) != 0) | ~ballot64(have);
+            }
             const u32 olen = have ? len : 0u;
             incl = wave_inclusive_scan(olen);
             drel = incl - olen;                                         // the tag's first output byte, from the batch's
@@ -269,13 +298,23 @@ SNP_MARK(B_top);
             const bool big = is_lit & (len > 64u);
             const u64 okm = ballot64(ok & !big & (incl <= kStage));
             ne = okm == ~0ull ? 64u : static_cast<u32>(__builtin_ctzll(~okm));
+            taken = ne;                                                 // tags, not slots:
+            if (dealt) {
+                if (ne && !((last >> (ne - 1u)) & 1ull)) ne -= 1u;      // never between the two slots of a literal
+                taken = static_cast<u32>(__builtin_popcountll(last & (ne == 64u ? ~0ull : (1ull << ne) - 1ull)));
+            }
 SNP_MARK(B_ne0);
             if (ne == 0) {
                 // not a batch: a literal > 64 bytes goes by the whole wave, anything else to the serial loop -- after the held batch
-                const u32 f0 = read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), 0);
+                // (slots dealt out again: slot 0 may be the first half of a literal whose second half cannot be taken, or carry a clamped
+                //  length -- the WHOLE first tag is judged then, by the checks `ok` makes)
+                const u32 body0 = read_lane(body, 0);
+                const bool long0 = dealt && read_lane(is_lit ? 1u : 0u, 0) != 0u && len_tag0 > 64u;
+                const bool whole_ok = (len_tag0 - 1u) < room && body0 <= room - len_tag0 && static_cast<u64>(len_tag0) + 16u <= expected - op;
+                const u32 f0 = long0 ? (whole_ok ? 3u : 0u) : read_lane((ok ? 1u : 0u) | (big ? 2u : 0u), 0);
                 mode = f0 == 3u ? kModeLongLiteral : kModeLeave;
                 s_first = read_lane(pos, 0);
-                s_len0 = read_lane(len, 0);
+                s_len0 = dealt ? len_tag0 : read_lane(len, 0);         // (slot 0 is tag 0: its full length, whatever the slots say)
                 s_body0 = read_lane(body, 0) | (FRAG && read_lane(dead ? 1u : 0u, 0) ? 0x80000000u : 0u);
             }
         }
@@ -452,7 +491,7 @@ SNP_MARK(B_pass1);
         const bool early = act & live & (is_lit | far);
         const bool waits = act & live & !early & !near;
         if (FENCED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the write-outs before the held batch's are visible to this wave's loads
-        pf_at = emitted + ne;                                   // the next batch's tag bytes travel with this batch's loads
+        pf_at = emitted + taken;                                // the next batch's tag bytes travel with this batch's loads
         if (pf_at < ntok) q_pf = ld32u(src + wbase + c_pos[pf_at + lane < ntok ? pf_at + lane : pf_at]);
         const bool any_mid = ballot64(act & (len > 32u)) != 0ull;
         const u32 sofs_mine = is_lit ? wbase + body : op + drel - off;   // the source, from src (literals) or dst (copies)
@@ -491,7 +530,7 @@ SNP_MARK(B_stage);
             h_valid = true;
         }
         op += span;
-        emitted += ne;
+        emitted += taken;
     }
 SNP_MARK(Z_exit);
     B.ip = wbase;                                                       // (every exit leaves consumed = 0)
