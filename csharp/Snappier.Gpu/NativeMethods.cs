@@ -25,10 +25,10 @@ public enum SnpStatus : int
 /// <summary>snp_option (include/snappier_hip.h): per-context configuration; no option changes a result.</summary>
 public enum SnpOption : int
 {
-    DecodeLayout = 1,           // 0 by the previous batch, 1 one block per wavefront, 2 a lane per small block, 3/4/5 a team of 4/8/16 lanes
+    DecodeLayout = 1,           // 0 by the previous batch, 1 one block per wavefront, 2 a lane per small block, 3/4/5 a team of 4/8/16 lanes, 6 the serial kernel
     SmallBlockMax = 2,
     SmallBlockMinBatch = 3,
-    CompressLayout = 4,         // 0 by batch size, 2 fragment per lane (HBM tables), 3 fragment per wavefront (LDS table)
+    CompressLayout = 4,         // 0 by batch size, 2 fragment per lane (HBM tables), 3 fragment per wavefront (LDS table), 4 the same with the table in a global-memory slot
     CompressWindowMaxBatch = 5,
     TableProbeTries = 6,        // workspaces' worth of candidate pieces the DEVICE's hash-table workspace search may hold (default 2; 3..24 = the thorough search, 1 = a plain workspace of the context's own)
     TableProbeMaxBytes = 7,     // cap on the transient footprint of that search (default: half of free memory; an explicit cap is honoured up to 7/8)
@@ -36,6 +36,24 @@ public enum SnpOption : int
     Fenced = 9,
     DecodeLeftovers = 10,
     CrcKernel = 11,          // CRC-32C kernel: 0 = three LDS tables (default, 5.8 TB/s), 1 = table-free (1.7 TB/s), 2 = four 8-bit tables (round 3)
+    // launch shapes (round 6; snappier_hip.h explains each -- defaults are the measured best, no option changes a result)
+    CompressWindowPositions = 12,
+    CompressWindowGlobalMinBatch = 13,
+    CompressLaneStores = 14,
+    CompressLaneProbes = 15,
+    CompressLanesPerWavefront = 16,
+    CompressSlice = 17,
+    CompressSmallInputLds = 18,
+    CompressSmallInputLanes = 19,
+    FrameScan = 20,
+    DecodeLdsThrottle = 21,
+}
+
+/// <summary>Names this binding used before round 5 (same numbers).</summary>
+public static class SnpOptionCompat
+{
+    [System.Obsolete("renamed: SnpOption.CrcKernel (same number; 0 / 1 mean the same)")]
+    public const SnpOption CrcTableFree = SnpOption.CrcKernel;
 }
 
 public enum SnpHash : int

@@ -92,15 +92,17 @@ snp_status snp_ctx_synchronize(snp_ctx* ctx);
 uint64_t snp_ctx_counter(const snp_ctx* ctx, int which);
 
 /* Per-context configuration.  A library loaded into a long-running service is configured through these, per context and at any
- * time between calls (the SNAPPIER_HIP_* environment variables, read once by snp_ctx_create, remain as debug overrides and only
- * set the initial values).  No option changes a RESULT -- bytes, lengths and status codes are the same under every setting
+ * time between calls.  The library reads NO environment variable (the SNAPPIER_HIP_* knobs of the A/B scripts exist only in variant
+ * builds made with -DSNAPPIER_HIP_DEBUG_ENV, scripts/build_variant.sh).  No option changes a RESULT -- bytes, lengths and status codes are the same under every setting
  * (tests/test_gpu_parity.py, tests/test_gpu_fuzz.py run every layout against the oracle); they choose kernels and memory behaviour.
  * snp_ctx_set_option returns SNP_ERR_BAD_ARG for an unknown option or a value outside its range and changes nothing then. */
 typedef enum snp_option {
     /* How snp_decompress_batch lays a batch out.  0 (default): by what the context's PREVIOUS batch looked like -- small blocks
      * (<= SNP_OPT_SMALL_BLOCK_MAX declared bytes) by a lane or a team of lanes each, the rest one block per wavefront; a workload
      * that alternates between block sizes should pin the layout per call instead: 1 = one block per wavefront only (no small-block
-     * pre-pass), 2 = pre-pass with one lane per block, 3 / 4 / 5 = pre-pass with a team of 4 / 8 / 16 lanes per block. */
+     * pre-pass), 2 = pre-pass with one lane per block, 3 / 4 / 5 = pre-pass with a team of 4 / 8 / 16 lanes per block;
+     * 6 = every block by the SERIAL kernel (decompress.hip: one wavefront walks the tags one at a time -- the reference's loop as it
+     * stands, SnappyDecompressor.cs:184-347; the parity baseline and a debugging aid, ~20 x slower). */
     SNP_OPT_DECODE_LAYOUT = 1,
     SNP_OPT_SMALL_BLOCK_MAX = 2,        /* bytes; blocks declaring at most this many take the pre-pass (0 = never; default 512) */
     SNP_OPT_SMALL_BLOCK_MIN_BATCH = 3,  /* ... in batches of at least this many blocks (default 4096) */
@@ -137,8 +139,27 @@ typedef enum snp_option {
      * 11 + 11 + 10 bits out of three tables in LDS (5.6-5.9 TB/s; batches too small to amortise the table copy take form 2); 1 = TABLE-FREE, the
      * map applied bit by bit in registers (1.7 TB/s: VALU-bound; gfx950 has neither a CRC instruction nor a carry-less multiply);
      * 2 = round 3's four 256-entry tables (5.3 TB/s).  Same results. */
-    SNP_OPT_CRC_KERNEL = 11
+    SNP_OPT_CRC_KERNEL = 11,
+    /* ---- launch shapes (round 6: every path the library contains is reachable through an option, so that the parity tests exercise the
+     * shipped binary; the defaults are the measured best and nothing below changes a result) ---- */
+    SNP_OPT_COMPRESS_WINDOW_POSITIONS = 12,        /* per-wavefront compressor: window positions per lane, 1 (default) | 2 (measured slower: 58 % of its rounds are cut) */
+    SNP_OPT_COMPRESS_WINDOW_GLOBAL_MIN_BATCH = 13, /* layout 0: window-kernel batches of at least this many fragments keep their table in a global-memory slot (default 4096) */
+    /* Lane compressor, how a lane's output and probes are issued: -1 (default) by batch size, else a mask -- 1: a short literal may leave as one
+     * 16-byte store that overshoots inside MaxCompressedLength, 2: tag + body of a literal in one store, 4: a copy tag as one 4-byte store,
+     * 8: 16- instead of 32-byte match-extension trips, 16: output staged per lane in LDS and written in 64-byte runs, 64: probe + insert as
+     * one atomic exchange (one probe per trip only), 128: probe bytes from a 16-byte register window; 0 = exact-length stores only. */
+    SNP_OPT_COMPRESS_LANE_STORES = 14,
+    SNP_OPT_COMPRESS_LANE_PROBES = 15,             /* lane compressor: probes of a lane's scan issued together, 0 (default: 1 from 131 072 fragments, else 2) | 1..4 */
+    SNP_OPT_COMPRESS_LANES_PER_WAVEFRONT = 16,     /* lane compressor: fragments per wavefront, 0 (default: 64 / 32 / 16 by batch size) | 8 | 16 | 32 | 64 */
+    SNP_OPT_COMPRESS_SLICE = 17,                   /* lane compressor: fragments per launch (>= 4096; default 262144) -- larger batches run in slices */
+    /* Lane compressor on batches of SMALL fragments: a launch that first copies each fragment into LDS.  -1 (default): when the previous
+     * batch's longest fragment lay in (80, 768] bytes; 0 never; else the LDS slot in bytes (<= 2048; fragments up to that long take it). */
+    SNP_OPT_COMPRESS_SMALL_INPUT_LDS = 18,
+    SNP_OPT_COMPRESS_SMALL_INPUT_LANES = 19,       /* ... its lanes per wavefront: 0 (default 32) | 16 | 32 | 64 */
+    SNP_OPT_FRAME_SCAN = 20,                       /* snp_frame_decode_device header walk: 0 (default) spans walked concurrently, 1 one lane, serial */
+    SNP_OPT_DECODE_LDS_THROTTLE = 21               /* bytes of dynamic LDS requested per decode wavefront purely to cap wavefronts per CU (0 = none; measurements) */
 } snp_option;
+#define SNP_OPT_CRC_TABLE_FREE SNP_OPT_CRC_KERNEL   /* deprecated name (rounds 1-4); same number, values 0 / 1 mean the same */
 snp_status snp_ctx_set_option(snp_ctx* ctx, int option, int64_t value);
 snp_status snp_ctx_get_option(const snp_ctx* ctx, int option, int64_t* out_value);
 /* Builds the device's hash-table workspace for batches of up to `nfragments` 64 KiB fragments NOW instead of on the first large

@@ -20,19 +20,26 @@ def check_bits(d):
 def count(f: bytes, variant: int):
     n = len(f)
     c = dict(probes=0, inserts=0, cand_loads_u32_check=0, cand_loads_u16=0, matches=0, check_false_positives=0, pos0_probes=0,
-             insert_probe_same_sector64=0, insert_probe_same_sector32=0, insert_probe_pairs=0)
+             insert_probe_same_sector64=0, insert_probe_same_sector32=0, insert_probe_pairs=0,
+             probe_first_touch=0, insert_first_touch=0, probe_first_touch_group4=0, probe_first_touch_group16=0)   # (round 6: the "never-written bucket" filter)
     H = M.h_crc if variant == M.HASH_CRC32C else M.h_mul
     ld32 = lambda p: int.from_bytes(f[p:p + 4], "little")   # noqa: E731
     ts = M.tsize(n)
     mask = 2 * (ts - 1)
     table = [0] * ts
     chk = [0] * ts                                          # the check bits the device entry carries
+    written = [False] * ts                                  # has this bucket ever been written?  (1 bit per bucket = 2 KiB per fragment; per 4 / 16 buckets: 512 / 128 B)
+    wr4, wr16 = [False] * (ts // 4 + 1), [False] * (ts // 16 + 1)
 
     def probe(p, d):
         h = H(d, mask) >> 1                                 # (pymodel's H returns a byte offset into a u16 table)
         cand, cc = table[h], chk[h]
         table[h], chk[h] = p, check_bits(d)
         c["probes"] += 1
+        c["probe_first_touch"] += 0 if written[h] else 1    # the answer (0) is known without a fetch, the insert can be a plain store
+        c["probe_first_touch_group4"] += 0 if wr4[h >> 2] else 1
+        c["probe_first_touch_group16"] += 0 if wr16[h >> 4] else 1
+        written[h] = wr4[h >> 2] = wr16[h >> 4] = True
         hit = ld32(cand) == d
         if cand == 0 and cc == 0:
             c["pos0_probes"] += 1                           # zero-initialised entry: compared with the fragment's first four bytes in a register
@@ -95,6 +102,8 @@ def count(f: bytes, variant: int):
                 hm1 = H(dm1, mask) >> 1
                 table[hm1], chk[hm1] = ip - 1, check_bits(dm1)
                 c["inserts"] += 1
+                c["insert_first_touch"] += 0 if written[hm1] else 1
+                written[hm1] = wr4[hm1 >> 2] = wr16[hm1 >> 4] = True
                 cand, hit, h = probe(ip, ld32(ip))
                 c["insert_probe_pairs"] += 1
                 c["insert_probe_same_sector64"] += 1 if (hm1 >> 4) == (h >> 4) else 0
@@ -126,6 +135,8 @@ def main():
         row["table_accesses_per_fragment"] = round((tot["probes"] + tot["inserts"]) / k, 1)
         row["u16_tables_extra_random_loads_per_fragment"] = round((tot["cand_loads_u16"] - tot["cand_loads_u32_check"]) / k, 1)
         row["u16_tables_accesses_vs_now"] = round((tot["probes"] + tot["inserts"] + tot["cand_loads_u16"]) / (tot["probes"] + tot["inserts"] + tot["cand_loads_u32_check"]), 3)
+        row["first_touch_share_of_probes"] = round(tot["probe_first_touch"] / max(tot["probes"], 1), 4)
+        row["first_touch_share_of_accesses"] = round((tot["probe_first_touch"] + tot["insert_first_touch"]) / max(tot["probes"] + tot["inserts"], 1), 4)
         row["same_sector64_share_of_pairs"] = round(tot["insert_probe_same_sector64"] / max(tot["insert_probe_pairs"], 1), 5)
         print(json.dumps(row), flush=True)
 

@@ -19,7 +19,7 @@
 // instruction issue.  Batches below 16 384 fragments use compress_win.hip (one wavefront per fragment is better there).
 #include <cstdlib>
 
-#include "../snp_device.h"
+#include "snp_device.h"
 
 #ifndef SNP_CL_FLAT
 #define SNP_CL_FLAT 1     // 1: flat per-lane state machine (default); 0: the reference's nested loops, verbatim
@@ -746,9 +746,10 @@ __global__ __launch_bounds__(256) void k_max_len(const u32* __restrict__ in_len,
 
 extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                                 const u64* out_off, u32* out_len, i32* status, int variant,
-                                                int emit_varint, const snp_table_pieces* tables, u32* max_len, hipStream_t stream, int lanes_per_wave)
+                                                int emit_varint, const snp_table_pieces* tables, u32* max_len, hipStream_t stream, const snp_lane_tuning* tune)
 {
     if (nblocks == 0) return hipSuccess;
+    int lanes_per_wave = tune->hint;                                     // (this file predates SNP_OPT_COMPRESS_LANE_*: it goes by the hint and its environment knobs)
     hipError_t e = snp_zero_words_async(max_len, 1, stream);
     if (e != hipSuccess) return e;
     const u32 mgrid = (nblocks + 255) / 256 < 1024 ? (nblocks + 255) / 256 : 1024u;

@@ -38,7 +38,7 @@
 // lane walks a chain of tags through its own 32 bytes, chains that meet are the same chain from there on -- and executes
 // 64 tags at a time straight from the resulting list (see the block comment at `if (FRONT == 3)`).
 // FRAG = true decodes one 64 KiB fragment of a larger block from a tag start found by tag_index.hip (FRONT 0 or 2).
-#include "../snp_device.h"
+#include "snp_device.h"
 
 namespace {
 

@@ -5,6 +5,7 @@ not straddling the batch start), the rest by reason -- and how many further lane
 import os, sys, json, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab"))
 import numpy as np
 from oracle import pyoracle as O
 from ring_model import parse_tags

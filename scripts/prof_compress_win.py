@@ -2,7 +2,7 @@
 SNAPPIER_HIP_LIB).  BLOCKS, DATA=html|low|mixed, NP=1|2."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SNAPPIER_HIP_COMPRESS"] = "win"
+os.environ["SNAPPIER_HIP_COMPRESS"] = os.environ.get("SNAPPIER_HIP_COMPRESS_FORM", "win")
 os.environ["SNAPPIER_HIP_WIN_NP"] = os.environ.get("NP", "2")
 import torch
 import snappier_amd as S
@@ -35,7 +35,7 @@ v = [int(x) for x in buf]
 names = {0: "dense rounds", 1: "cuts", 2: "tokens", 3: "wave extends", 4: "sparse rounds", 5: "sparse cuts",
          8: "window load", 9: "hash+table", 10: "cand gather+16B", 11: "wave extension", 12: "walk", 13: "publish/cut/queue",
          14: "emit batch", 15: "loop head / sparse"}
-out = {"data": kind, "np": os.environ["SNAPPIER_HIP_WIN_NP"], "blocks": nb, "ms": round(ms, 2)}
+out = {"form": os.environ["SNAPPIER_HIP_COMPRESS"], "data": kind, "np": os.environ["SNAPPIER_HIP_WIN_NP"], "blocks": nb, "ms": round(ms, 2)}
 for k, nme in names.items():
     out[nme] = round(v[k] / nb, 1)
 tot = sum(v[8:16])

@@ -14,7 +14,7 @@ import re
 import torch  # noqa: F401  (must precede CDLL -- see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SNAPPIER_HIP_LIB") or os.path.join(HERE, "libsnappier_hip.so")   # override: kernel-variant A/B runs (a LAB=1 build, if knobs are to act)
+LIB_PATH = os.environ.get("SNAPPIER_HIP_LIB") or os.path.join(HERE, "libsnappier_hip.so")   # override: kernel-variant A/B runs (scripts/build_variant.sh)
 HEADER_PATH = os.path.join(HERE, "..", "include", "snappier_hip.h")
 
 (OK, ERR_OUTPUT_TOO_SMALL, ERR_BAD_OFFSET, ERR_TOO_LONG, ERR_INCOMPLETE, ERR_BAD_LENGTH, ERR_CRC_MISMATCH,
@@ -24,7 +24,14 @@ BLOCK_SIZE = 65536
 MAX_BLOCK_COMPRESSED = 76491
 # snp_option (include/snappier_hip.h)
 (OPT_DECODE_LAYOUT, OPT_SMALL_BLOCK_MAX, OPT_SMALL_BLOCK_MIN_BATCH, OPT_COMPRESS_LAYOUT, OPT_COMPRESS_WINDOW_MAX_BATCH,
- OPT_TABLE_PROBE_TRIES, OPT_TABLE_PROBE_MAX_BYTES, OPT_PARALLEL_DECODE_MIN, OPT_FENCED, OPT_DECODE_LEFTOVERS, OPT_CRC_KERNEL) = range(1, 12)
+ OPT_TABLE_PROBE_TRIES, OPT_TABLE_PROBE_MAX_BYTES, OPT_PARALLEL_DECODE_MIN, OPT_FENCED, OPT_DECODE_LEFTOVERS, OPT_CRC_KERNEL,
+ OPT_COMPRESS_WINDOW_POSITIONS, OPT_COMPRESS_WINDOW_GLOBAL_MIN_BATCH, OPT_COMPRESS_LANE_STORES, OPT_COMPRESS_LANE_PROBES,
+ OPT_COMPRESS_LANES_PER_WAVEFRONT, OPT_COMPRESS_SLICE, OPT_COMPRESS_SMALL_INPUT_LDS, OPT_COMPRESS_SMALL_INPUT_LANES, OPT_FRAME_SCAN,
+ OPT_DECODE_LDS_THROTTLE) = range(1, 22)
+OPT_CRC_TABLE_FREE = OPT_CRC_KERNEL     # deprecated name (rounds 1-4), same number
+# SNP_OPT_DECODE_LAYOUT / SNP_OPT_COMPRESS_LAYOUT values
+DECODE_AUTO, DECODE_WAVE_ONLY, DECODE_SMALL_LANES, DECODE_SMALL_TEAM4, DECODE_SMALL_TEAM8, DECODE_SMALL_TEAM16, DECODE_SERIAL = range(7)
+COMPRESS_AUTO, COMPRESS_LANES, COMPRESS_WINDOW_LDS, COMPRESS_WINDOW_GLOBAL = 0, 2, 3, 4
 
 
 def declared_symbols() -> list[str]:
@@ -38,38 +45,35 @@ def declared_symbols() -> list[str]:
 _lib = None
 _lab = None
 LAB_PATH = os.path.join(HERE, "variants", "libsnappier_hip_lab.so")
-# what selects the LAB library (see lib()): every SNAPPIER_HIP_* knob except the library override itself
-_NOT_KNOBS = ("SNAPPIER_HIP_LIB",)
 
 
-def debug_knobs_set() -> bool:
-    return any(k.startswith("SNAPPIER_HIP_") and k not in _NOT_KNOBS for k in os.environ)
+def lab_requested() -> bool:
+    """SNAPPIER_HIP_LAB=1: the explicit opt-in of the A/B scripts (scripts/) to the LAB library -- the product sources built with
+    -DSNAPPIER_HIP_DEBUG_ENV plus the round-4 decoder front ends of scripts/lab/, the only build in which the SNAPPIER_HIP_* knobs act."""
+    return os.environ.get("SNAPPIER_HIP_LAB", "") == "1"
 
 
 def lab_path() -> str:
-    """snappier_amd/variants/libsnappier_hip_lab.so, built on demand (LAB=1 scripts/build_variant.sh lab: the product sources with
-    -DSNAPPIER_HIP_DEBUG_ENV plus the decoder front ends of csrc/lab/)."""
-    import subprocess
-    script = os.path.join(HERE, "..", "scripts", "build_variant.sh")
-    srcs = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hip", ".h"))]
-    srcs += [os.path.join(HERE, "csrc", "lab", f) for f in os.listdir(os.path.join(HERE, "csrc", "lab"))]
-    srcs.append(os.path.join(HERE, "..", "include", "snappier_hip.h"))
-    if not os.path.exists(LAB_PATH) or any(os.path.getmtime(f) > os.path.getmtime(LAB_PATH) for f in srcs):
-        r = subprocess.run(["bash", script, "lab"], env=dict(os.environ, LAB="1"), capture_output=True, text=True)
-        if r.returncode != 0:
-            raise ImportError("building the lab library failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+    """snappier_amd/variants/libsnappier_hip_lab.so -- built by `LAB=1 bash scripts/build_variant.sh lab`, never implicitly (no compiler runs at import)."""
+    if not os.path.exists(LAB_PATH):
+        raise ImportError(f"{LAB_PATH} is missing: SNAPPIER_HIP_LAB=1 asks for the lab library; build it with `LAB=1 bash scripts/build_variant.sh lab`")
     return LAB_PATH
 
 
 def lib() -> C.CDLL:
-    """The product library -- or, while any SNAPPIER_HIP_* knob is set in the environment (tests and A/B scripts that vary a kernel
-    layout), the LAB library, which is the only one that reads them.  A Context remembers the library it was created from."""
+    """The product library (libsnappier_hip.so, or the file SNAPPIER_HIP_LIB names).  It reads no environment: kernels and layouts are chosen per
+    context through snp_ctx_set_option (Context.set_option).  Only with SNAPPIER_HIP_LAB=1 -- the A/B scripts -- is the LAB library loaded
+    instead; a stray SNAPPIER_HIP_* variable without it is ignored, with a warning.  A Context remembers the library it was created from."""
     global _lib, _lab
-    if not os.environ.get("SNAPPIER_HIP_LIB") and debug_knobs_set():
+    if not os.environ.get("SNAPPIER_HIP_LIB") and lab_requested():
         if _lab is None:
             _lab = _load(lab_path())
         return _lab
     if _lib is None:
+        stray = sorted(k for k in os.environ if k.startswith("SNAPPIER_HIP_") and k not in ("SNAPPIER_HIP_LIB", "SNAPPIER_HIP_LAB"))
+        if stray and not os.environ.get("SNAPPIER_HIP_LIB"):
+            import warnings
+            warnings.warn(f"{', '.join(stray)} ignored: libsnappier_hip.so reads no environment (use Context.set_option, or SNAPPIER_HIP_LAB=1 for the lab build)")
         _lib = _load(LIB_PATH)
     return _lib
 

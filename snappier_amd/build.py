@@ -15,7 +15,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fco
          "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib"]
 
 LIBS = {
-    "libsnappier_hip.so": ["decode_chains.hip", "decompress.hip", "decompress_small.hip", "tag_index.hip", "compress_lanes.hip", "compress_win.hip", "crc32c.hip", "framing.hip", "frame_scan.hip", "capi.hip"],
+    "libsnappier_hip.so": ["decode_chains.hip", "decompress.hip", "decompress_small.hip", "tag_index.hip", "compress_lanes.hip", "compress_win.hip", "crc32c.hip", "framing.hip", "frame_scan.hip",
+                           "capi_ctx.hip", "capi_pool.hip", "capi_batch.hip", "capi_host.hip", "capi_frame.hip"],
     "libsnappier_datagen.so": ["datagen.hip"],
 }
 

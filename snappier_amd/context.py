@@ -17,7 +17,7 @@ class Context:
         """stream: a hipStream_t handle as an int (torch.cuda.current_stream().cuda_stream; 0 = the default stream),
         or None for a private non-blocking stream owned by the context."""
         self._h = C.c_void_p()
-        self.lib = N.lib()          # (the product library, or the lab one while a SNAPPIER_HIP_* knob is set: every call on this context goes to it)
+        self.lib = N.lib()          # (the product library -- or the lab one under SNAPPIER_HIP_LAB=1: every call on this context goes to the library it was created from)
         st = self.lib.snp_ctx_create(device, hash_variant, None, C.byref(self._h))
         if st != N.OK:
             self._h = C.c_void_p()
@@ -87,7 +87,7 @@ def default_context(hash_variant: int | None = None) -> Context:
     cache = getattr(_tls, "ctx", None)
     if cache is None:
         cache = _tls.ctx = {}
-    key = (key, N.debug_knobs_set())       # (a context belongs to the library it was created from)
+    key = (key, N.lab_requested())         # (a context belongs to the library it was created from)
     if key not in cache:
         cache[key] = Context(0, key[0])
     return cache[key]

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void k_max_len(const u32* __restrict__ in_len,
 
 extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
                                                 const u64* out_off, u32* out_len, i32* status, int variant,
-                                                int emit_varint, const snp_table_pieces* tables, u32* max_len, hipStream_t stream, int lanes_per_wave)
+                                                int emit_varint, const snp_table_pieces* tables, u32* max_len, hipStream_t stream, const snp_lane_tuning* tune)
 {
     if (nblocks == 0) return hipSuccess;
     hipError_t e = snp_zero_words_async(max_len, 1, stream);
@@ -716,11 +716,13 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     hipLaunchKernelGGL(k_max_len, dim3(mgrid), dim3(256), 0, stream, in_len, nblocks, max_len);
     // Fragments per wavefront: 64 when there are enough fragments to fill the chip that way; fewer (partially filled
     // wavefronts, more of them) for mid-sized batches, so that every CU gets several wavefronts to overlap latency.
+    // (`tune`: the context's SNP_OPT_COMPRESS_LANE_* settings and its hint from the previous batch; the SNAPPIER_HIP_* variables below exist in
+    //  variant builds only -- SNP_GETENV is a null pointer in the product library)
     const char* env = SNP_GETENV("SNAPPIER_HIP_LANES_PER_WAVE");
-    const bool two_probes = (lanes_per_wave & 256) != 0;               // the context's hint: small fragments (capi.hip)
-    const u32 small_hint = ((static_cast<u32>(lanes_per_wave) >> 9) & 63u) << 4;   // ... and, when they are small enough for it, the LDS slot size of the SMALL launch
-    lanes_per_wave &= 255;
-    u32 per = env ? static_cast<u32>(atoi(env)) : lanes_per_wave ? static_cast<u32>(lanes_per_wave) : (nblocks >= 131072 ? 64u : nblocks >= 8192 ? 32u : 16u);   // measured: scripts/sweep_layouts.py
+    const bool two_probes = (tune->hint & 256) != 0;                    // the context's hint: small fragments (capi_batch.hip)
+    const u32 small_hint = ((static_cast<u32>(tune->hint) >> 9) & 63u) << 4;   // ... and, when they are small enough for it, the LDS slot size of the SMALL launch
+    const u32 lanes_hint = tune->lanes_per_wave ? static_cast<u32>(tune->lanes_per_wave) : static_cast<u32>(tune->hint & 255);
+    u32 per = env ? static_cast<u32>(atoi(env)) : lanes_hint ? lanes_hint : (nblocks >= 131072 ? 64u : nblocks >= 8192 ? 32u : 16u);   // measured: scripts/sweep_layouts.py
     if (per != 64 && per != 32 && per != 16 && per != 8) per = 64;
     const u32 grid = (nblocks + per - 1) / per;
     // Output-store options (bit 0: a short literal may overshoot with one 16-byte store, bit 1: tag + body of a literal in
@@ -734,25 +736,26 @@ extern "C" hipError_t snp_launch_compress_lanes(const u8* in, const u64* in_off,
     const char* ex = SNP_GETENV("SNAPPIER_HIP_EXACT_LITERALS");
     const char* oe = SNP_GETENV("SNAPPIER_HIP_CL_OPTS");
     // (the LDS staging pays once the memory system is saturated: same-process A/B, 16 384 fragments 37.4 vs 35.5 ms, 65 536: 59.7 vs 61.1)
-    const int opts = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0)));   // (kOptExchangeProbe acts in one-probe-per-trip launches only)
+    const int opts = ((ex && ex[0] == '1') ? 0 : oe ? (atoi(oe) & 255) : tune->opts >= 0 ? (tune->opts & 255)
+                      : ((nblocks >= 32768 ? 23 : 7) | 64 | ((nblocks >= 131072 && !two_probes) ? 128 : 0)));   // (kOptExchangeProbe acts in one-probe-per-trip launches only)
     // probes issued together per scan trip (SNAPPIER_HIP_CL_SLOTS=1|2, read per launch; default SNP_CL_SLOTS)
     const char* se = SNP_GETENV("SNAPPIER_HIP_CL_SLOTS");
     // (two probes per trip hide latency while the batch is too small to saturate memory: 10 % faster up to 65 536 fragments;
     // one probe is 1.5 % faster at 163 840)
     // (... and for batches of SMALL fragments at any size -- bit 8 of lanes_per_wave is the context's hint for them: they are latency-bound, not
     // request-bound: 256-byte blocks 40.7 GB/s with one exchange probe per trip, 46.5 with two speculative probes, profiles/r03p_small_compress_sweep.jsonl)
-    const u32 slots = se ? static_cast<u32>(atoi(se)) : ((nblocks >= 131072 && !two_probes) ? kDefaultSlots : 2u);
+    const u32 slots = se ? static_cast<u32>(atoi(se)) : tune->probes > 0 ? static_cast<u32>(tune->probes) : ((nblocks >= 131072 && !two_probes) ? kDefaultSlots : 2u);
     // The context's hint: the longest fragment of the previous launch, rounded up to 16 bytes, when it lay in (80, 768] (bits 9-14 of
     // lanes_per_wave; measured, profiles/r03y_small_compress_lds_input_sweep.txt: 96 B 41.0 -> 42.8 GB/s, 128 B 42.2 -> 47.2, 256 B 48.1 -> 60.1-61.6,
     // 512 B 47.8 -> 60.7-62.6, 768 B 49.6 -> 51.3; 64 B and 1 KiB lose).  The launch with the input in LDS goes first; each of the two launches
     // checks max_len on the device and returns if the batch is the other one's.  SNAPPIER_HIP_CL_SMALL=0 never launches it, =<bytes> forces
     // its slot size; SNAPPIER_HIP_CL_SMALL_PER = its lanes per wavefront.
     const char* sm = SNP_GETENV("SNAPPIER_HIP_CL_SMALL");
-    u32 small_max = sm ? (static_cast<u32>(atoi(sm)) + 15u) & ~15u : small_hint;
+    u32 small_max = sm ? (static_cast<u32>(atoi(sm)) + 15u) & ~15u : tune->small_bytes >= 0 ? (static_cast<u32>(tune->small_bytes) + 15u) & ~15u : small_hint;
     if (small_max > 2048) small_max = 0;
     if (small_max) {
         const char* sp = SNP_GETENV("SNAPPIER_HIP_CL_SMALL_PER");
-        u32 sper = sp ? static_cast<u32>(atoi(sp)) : 32u;
+        u32 sper = sp ? static_cast<u32>(atoi(sp)) : tune->small_lanes ? static_cast<u32>(tune->small_lanes) : 32u;
         if (sper != 64 && sper != 32 && sper != 16) sper = 32;
         const u32 sgrid = (nblocks + sper - 1) / sper;
         const u32 dyn = sper * (small_max + 16u + kStageStride);

@@ -33,6 +33,17 @@ struct snp_table_pieces {
     uint32_t n;
 };
 
+// Launch shape of the lane compressor (compress_lanes.hip), per context: SNP_OPT_COMPRESS_LANE_* (include/snappier_hip.h).  0 / -1 = chosen
+// from the batch size and the context's hint; results never depend on it (tests/test_gpu_parity.py runs every combination against the oracle).
+struct snp_lane_tuning {
+    int lanes_per_wave;   // 0 auto | 8 | 16 | 32 | 64 fragments per wavefront
+    int opts;             // -1 auto | a mask of the kernel's kOpt* bits (0..255)
+    int probes;           // 0 auto | 1..4 probes of one lane's scan issued together
+    int small_bytes;      // -1 auto (the hint) | 0 never | LDS slot bytes of the launch that keeps small fragments' input in LDS (<= 2048)
+    int small_lanes;      // 0 auto (32) | 16 | 32 | 64 lanes per wavefront of that launch
+    int hint;             // what the context learnt from its previous batch: 32 = fragments <= 512 B, 256 = <= 4 KiB, bits 9-14 = (longest + 15) / 16 when in (80, 768]
+};
+
 // Unaligned little-endian accesses.  gfx950 under HSA runs in unaligned-access mode, so a dword access at any byte
 // address is one global_load_dword / global_store_dword (the packed struct tells the compiler align = 1).
 struct __attribute__((packed)) snp_u32_unaligned { u32 v; };

@@ -194,8 +194,19 @@ int main(int argc, char** argv)
         int64_t v = -1;
         EXPECT(get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 0);
         EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 4) == SNP_OK && get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 4);
-        EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 6) == SNP_ERR_BAD_ARG && get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 4);
-        EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 0) == SNP_OK);
+        EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 7) == SNP_ERR_BAD_ARG && get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 4);
+        EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 6) == SNP_OK && get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 6);   /* the serial kernel */
+        EXPECT(set_option(ctx, SNP_OPT_DECODE_LAYOUT, 0) == SNP_OK && get_option(ctx, SNP_OPT_DECODE_LAYOUT, &v) == SNP_OK && v == 0);
+        /* the launch-shape options of round 6: defaults, round trips, ranges; the deprecated name of option 11 still compiles */
+        EXPECT(get_option(ctx, SNP_OPT_COMPRESS_LANE_STORES, &v) == SNP_OK && v == -1 && get_option(ctx, SNP_OPT_COMPRESS_SMALL_INPUT_LDS, &v) == SNP_OK && v == -1);
+        EXPECT(set_option(ctx, SNP_OPT_COMPRESS_LANE_STORES, 256) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_COMPRESS_LANE_STORES, 87) == SNP_OK &&
+               get_option(ctx, SNP_OPT_COMPRESS_LANE_STORES, &v) == SNP_OK && v == 87 && set_option(ctx, SNP_OPT_COMPRESS_LANE_STORES, -1) == SNP_OK);
+        EXPECT(set_option(ctx, SNP_OPT_COMPRESS_LANE_PROBES, 5) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_COMPRESS_LANES_PER_WAVEFRONT, 24) == SNP_ERR_BAD_ARG &&
+               set_option(ctx, SNP_OPT_COMPRESS_SLICE, 100) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_COMPRESS_WINDOW_POSITIONS, 3) == SNP_ERR_BAD_ARG &&
+               set_option(ctx, SNP_OPT_FRAME_SCAN, 2) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_DECODE_LDS_THROTTLE, -1) == SNP_ERR_BAD_ARG);
+        EXPECT(get_option(ctx, SNP_OPT_COMPRESS_SLICE, &v) == SNP_OK && v == 262144 && get_option(ctx, SNP_OPT_COMPRESS_WINDOW_GLOBAL_MIN_BATCH, &v) == SNP_OK && v == 4096);
+        EXPECT(SNP_OPT_CRC_TABLE_FREE == SNP_OPT_CRC_KERNEL && set_option(ctx, SNP_OPT_CRC_TABLE_FREE, 1) == SNP_OK && get_option(ctx, SNP_OPT_CRC_KERNEL, &v) == SNP_OK && v == 1 &&
+               set_option(ctx, SNP_OPT_CRC_KERNEL, 0) == SNP_OK);
         EXPECT(set_option(ctx, SNP_OPT_TABLE_PROBE_MAX_BYTES, (int64_t)32 << 30) == SNP_OK && get_option(ctx, SNP_OPT_TABLE_PROBE_MAX_BYTES, &v) == SNP_OK && v == ((int64_t)32 << 30));
         EXPECT(set_option(ctx, SNP_OPT_TABLE_PROBE_TRIES, 0) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_TABLE_PROBE_TRIES, 3) == SNP_OK);
         EXPECT(get_option(ctx, SNP_OPT_SMALL_BLOCK_MAX, &v) == SNP_OK && v == 512);

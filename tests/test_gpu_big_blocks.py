@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     import snappier_amd as S
     from snappier_amd.errors import InvalidDataException
+    from snappier_amd import _native as N
     Snappy = S.Snappy
 
 
@@ -54,11 +55,12 @@ def low_entropy_bytes(n: int) -> bytes:
 
 
 @pytest.fixture(params=["default", "min1", "off"])
-def ctx(request, monkeypatch):
-    """default: parallel path from 256 KiB; min1: every block takes the parallel path; off: never."""
+def ctx(request):
+    """default: parallel path from 256 KiB; min1: every block takes the parallel path; off: never.  (An option of the PRODUCT library: the
+    fragment decoder these tests assert counters 0 / 1 / 6 of is decode_chains.hip's k_decode_chains_frag.)"""
     par_min = {"default": 262144, "min1": 1, "off": 0}[request.param]
-    monkeypatch.setenv("SNAPPIER_HIP_PARALLEL_MIN", str(par_min))       # explicit, whatever the caller's environment says
     c = S.Context(0, O.HASH_CRC32C)
+    c.set_option(N.OPT_PARALLEL_DECODE_MIN, par_min)
     c.par_min = par_min
     return c
 
@@ -141,15 +143,18 @@ def test_big_block_output_too_small(ctx):
     assert ok and written == len(data) and out[:written].tobytes() == data
 
 
-def test_big_block_all_decoder_variants(monkeypatch):
+def test_big_block_all_decoder_variants():
+    """One 3 MiB block through the fragment form of the default decoder and of the serial kernel, fenced and not: the same bytes, and the
+    fragment path really ran (counter 0) -- on the product library."""
     data = corpus_bytes(3 << 20)
     comp = O.compress(data, O.HASH_CRC32C)
-    for decode in ("chains", "ring", "queued", "serial", "batched"):
-        for fenced in ("0", "1"):
-            monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
-            monkeypatch.setenv("SNAPPIER_HIP_FENCED", fenced)
+    for decode in ("chains", "serial"):
+        for fenced in (0, 1):
             c = S.Context(0, O.HASH_CRC32C)
+            c.set_option(N.OPT_DECODE_LAYOUT, N.DECODE_SERIAL if decode == "serial" else N.DECODE_AUTO)
+            c.set_option(N.OPT_FENCED, fenced)
             assert Snappy.DecompressToArray(comp, c) == data, (decode, fenced)
+            assert c.counter(0) == 1 and c.counter(1) == 0, (decode, fenced)
 
 
 def test_contexts_are_independent_across_threads():
@@ -201,14 +206,14 @@ def test_work_follows_torch_streams():
     assert same and int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0
 
 
-def test_one_context_alternating_between_two_streams_keeps_its_scratch_ordered(monkeypatch):
+def test_one_context_alternating_between_two_streams_keeps_its_scratch_ordered():
     """The lane compressor's hash tables live in context-owned HBM scratch.  A context that is rebound from one torch
     stream to another (double buffering) must not let the second launch's memset + kernel run on the tables while the
     first is still using them: snp_ctx_set_stream orders the new stream behind the old one.  Both results must be the
     oracle's bytes."""
     from snappier_amd import batch as SB, datagen as SD
-    monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", "lanes")
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_LANES)
     html = read_testdata("html")
     nb = 4096
     raws = [SD.html_like_blocks(html, 100 + 7 * k, nb, "cuda") for k in range(4)]

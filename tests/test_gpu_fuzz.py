@@ -15,9 +15,11 @@ from conftest import read_testdata
 
 pytestmark = pytest.mark.gpu
 
+import layouts
+
 if torch.cuda.is_available():
     import snappier_amd as S
-    from snappier_amd import batch as SB
+    from snappier_amd import batch as SB, _native as N
 
 ROUNDS = int(os.environ.get("FUZZ_ROUNDS", "2"))
 BLOCKS = int(os.environ.get("FUZZ_BLOCKS", "768"))
@@ -97,11 +99,10 @@ def dev(a):
 
 @pytest.mark.parametrize("layout", ["win", "win2", "wing", "lanes"])
 @pytest.mark.parametrize("variant", [O.HASH_CRC32C, O.HASH_MUL])
-def test_fuzz_compress_bytes_equal_oracle(layout, variant, monkeypatch):
-    monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout)
-    monkeypatch.setenv("SNAPPIER_HIP_WIN_NP", "2" if layout == "win2" else "1")
+def test_fuzz_compress_bytes_equal_oracle(layout, variant):
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
     cd = SB.BlockCodec(0, variant)
+    layouts.set_compress_layout(cd.ctx, layout)
     for r in range(ROUNDS):
         rng = np.random.default_rng(SEED0 + 1000 * r + 17 * variant + (layout == "lanes"))
         blocks = [make_block(rng, text) for _ in range(BLOCKS)]
@@ -146,18 +147,11 @@ def corrupt(rng: np.random.Generator, z: np.ndarray) -> np.ndarray:
     return z
 
 
-@pytest.mark.parametrize("decode", ["queued", "chains", "ring", "batched", "serial", "small", "small-lanes", "small-team4", "small-team16"])
-def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatch):
-    if decode.startswith("small"):   # every block first goes through the small-block pre-pass (decompress_small.hip: 8 lanes per block, or the named layout)
-        if "-" in decode:
-            monkeypatch.setenv("SNAPPIER_HIP_SMALL", decode.split("-")[1])
-        monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
-        monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "65536")
-        monkeypatch.setenv("SNAPPIER_HIP_REDO", "list")           # always the pre-pass + list kernel, whatever the previous batch was like
-    else:
-        monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
+@pytest.mark.parametrize("decode", layouts.DECODE_LAYOUTS)
+def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode):
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    layouts.set_decode_layout(cd.ctx, decode)   # (small*: every block first goes through the small-block pre-pass -- decompress_small.hip: 8 lanes per block, or the named layout)
     for r in range(ROUNDS):
         rng = np.random.default_rng(SEED0 + 777 + r)
         blocks = [make_block(rng, text) for _ in range(BLOCKS)]
@@ -188,16 +182,13 @@ def test_fuzz_corrupted_streams_status_and_bytes_equal_oracle(decode, monkeypatc
 
 
 @pytest.mark.parametrize("layout", ["lanes", "team4", "team8", "team16"])
-def test_fuzz_small_blocks_corrupted_streams_equal_oracle(layout, monkeypatch):
+def test_fuzz_small_blocks_corrupted_streams_equal_oracle(layout):
     """The small-block pre-pass (decompress_small.hip) on what it is for: thousands of blocks of 1 .. 512 bytes, two thirds of them
     corrupted, through every layout (a lane, or a team of 4 / 8 / 16 lanes, per block); leftovers go to the list kernel.  Status,
     length and bytes of every block must equal the oracle's."""
-    monkeypatch.setenv("SNAPPIER_HIP_SMALL", layout)
-    monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
-    monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "512")
-    monkeypatch.setenv("SNAPPIER_HIP_REDO", "list")
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt") + read_testdata("geo.protodata"), dtype=np.uint8)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    layouts.set_decode_layout(cd.ctx, "small-" + layout, small_max=512)
     nb = 4 * BLOCKS
     for r in range(ROUNDS):
         rng = np.random.default_rng(SEED0 + 4242 + r)
@@ -256,14 +247,11 @@ TAXONOMY = [
 
 
 @pytest.mark.parametrize("layout", ["lanes", "team4", "team8", "team16"])
-def test_error_taxonomy_through_every_small_block_layout(layout, monkeypatch):
+def test_error_taxonomy_through_every_small_block_layout(layout):
     """The decoder's status vectors (test_decoder_error_taxonomy_matches_oracle) as a BATCH, so that the small-block pre-pass takes
     them, through every layout: status, length and bytes equal the oracle's whichever layout the policy would have picked, and
     nothing is written at or beyond out_len when the capacity is larger than the declared length."""
-    monkeypatch.setenv("SNAPPIER_HIP_SMALL", layout)
-    monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
-    monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "512")
-    monkeypatch.setenv("SNAPPIER_HIP_REDO", "list")
+    small_layout = "small-" + layout
     rng = np.random.default_rng(99)
     text = np.frombuffer(read_testdata("html"), dtype=np.uint8)
     streams, caps = [], []
@@ -287,6 +275,7 @@ def test_error_taxonomy_through_every_small_block_layout(layout, monkeypatch):
     ref, ref_len, ref_st = O.decompress_batch(sdata, s_off.astype(np.uint64), s_len.astype(np.uint32), out_off.astype(np.uint64),
                                               caps.astype(np.uint32), total, THREADS)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    layouts.set_decode_layout(cd.ctx, small_layout, small_max=512)
     for call in range(2):                                           # the second call runs under the policy the first one taught the context
         out = torch.full((total,), 0xA5, dtype=torch.uint8, device="cuda")
         dlen, dst = cd.decompress(dev(sdata), dev(s_off), dev(s_len), out, dev(out_off), dev(caps))
@@ -447,7 +436,7 @@ def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
 
 
 @pytest.mark.parametrize("variant", [O.HASH_CRC32C, O.HASH_MUL])
-def test_small_fragment_launch_with_input_in_lds_equals_oracle(variant, monkeypatch):
+def test_small_fragment_launch_with_input_in_lds_equals_oracle(variant):
     """Batches whose longest fragment is small take a second form of the lane compressor (fragment bytes in LDS, compress_lanes.hip
     SMALL) -- chosen from the PREVIOUS launch's longest fragment, verified on the device against this launch's.  Sequences that
     exercise every combination: no hint yet (general launch), hint and batch agree (LDS launch), a batch with a longer fragment after a
@@ -492,15 +481,15 @@ def test_small_fragment_launch_with_input_in_lds_equals_oracle(variant, monkeypa
     compared = 0
     for step, limit in enumerate([256, 256, 200, 512, 512, 4096, 96, 96, 768, 768, 1024, 300, 300, 65536, 256]):
         compared += check(batch(limit, 3000 if limit <= 4096 else 64), f"step {step}: fragments up to {limit} bytes")
-    for forced in ("0", "256", "128", "2000"):                           # the debug override: never / slot sizes that fit, do not fit, exceed the cap
-        monkeypatch.setenv("SNAPPIER_HIP_CL_SMALL", forced)
+    for forced in (0, 256, 128, 2000):                                   # SNP_OPT_COMPRESS_SMALL_INPUT_LDS: never / slot sizes that fit, do not fit, exceed what LDS holds at 32 lanes
+        cd.ctx.set_option(N.OPT_COMPRESS_SMALL_INPUT_LDS, forced)
         for limit in (256, 130):
-            compared += check(batch(limit, 2000), f"SNAPPIER_HIP_CL_SMALL={forced}, fragments up to {limit}")
-    monkeypatch.delenv("SNAPPIER_HIP_CL_SMALL")
-    for per in ("16", "64"):
-        monkeypatch.setenv("SNAPPIER_HIP_CL_SMALL_PER", per)
+            compared += check(batch(limit, 2000), f"SNP_OPT_COMPRESS_SMALL_INPUT_LDS={forced}, fragments up to {limit}")
+    cd.ctx.set_option(N.OPT_COMPRESS_SMALL_INPUT_LDS, -1)
+    for per in (16, 64):
+        cd.ctx.set_option(N.OPT_COMPRESS_SMALL_INPUT_LANES, per)
         for limit in (256, 256):
-            compared += check(batch(limit, 2000, exact=(per == "64")), f"{per} lanes per wavefront")
+            compared += check(batch(limit, 2000, exact=(per == 64)), f"{per} lanes per wavefront")
     log_session(test="small_fragment_launch_with_input_in_lds", hash_variant=variant, blocks_compared=compared, result="all equal")
 
 
@@ -533,10 +522,10 @@ def _compare_batch(cd, data, off, lens, variant, what):
     return nb
 
 
-def test_batches_beyond_one_launch_slice_equal_oracle(monkeypatch):
+def test_batches_beyond_one_launch_slice_equal_oracle():
     """A lane-compressor batch of more than 262 144 fragments runs as several launches over one hash-table workspace (capi.hip, slice_fragments), and
     the decoder's small-block pre-pass sees more blocks than any other test gives it: 600 000 blocks of 0..300 bytes in ONE call, every block equal to
-    the oracle and back.  Then the same seam at full fragment size: SNAPPIER_HIP_SLICE=4096 cuts 9 000 mixed fragments (up to 64 KiB) into three launches."""
+    the oracle and back.  Then the same seam at full fragment size: SNP_OPT_COMPRESS_SLICE = 4096 cuts 9 000 mixed fragments (up to 64 KiB) into three launches."""
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt") + read_testdata("geo.protodata"), dtype=np.uint8)
     rng = np.random.default_rng(262144)
     nb = 600000
@@ -553,12 +542,12 @@ def test_batches_beyond_one_launch_slice_equal_oracle(monkeypatch):
         cd = SB.BlockCodec(0, variant)
         compared += _compare_batch(cd, data, off, lens, variant, f"600 000 small blocks in one call, hash {variant}")
         assert cd.ctx.counter(2) >= 0
-    monkeypatch.setenv("SNAPPIER_HIP_SLICE", "4096")
-    monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", "lanes")
-    monkeypatch.setenv("SNAPPIER_HIP_TABLE_TRIES", "1")
     rng = np.random.default_rng(4096)
     blocks = [make_block(rng, text) for _ in range(9000)]
     d2, o2, l2 = batch_of(blocks)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    cd.ctx.set_option(N.OPT_COMPRESS_SLICE, 4096)
+    cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_LANES)
+    cd.ctx.set_option(N.OPT_TABLE_PROBE_TRIES, 1)
     compared += _compare_batch(cd, d2, o2, l2, O.HASH_CRC32C, "9 000 mixed fragments in slices of 4 096")
     log_session(test="batches_beyond_one_launch_slice", blocks_compared=compared, result="all equal, and back")

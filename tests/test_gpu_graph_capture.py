@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
     import snappier_amd as S
-    from snappier_amd import batch as SB, datagen as SD
+    from snappier_amd import batch as SB, datagen as SD, _native as N
     from snappier_amd.errors import InvalidOperationException
 
 
@@ -28,14 +28,15 @@ def _oracle_lengths(raw: torch.Tensor, nb: int, variant: int):
     return ref, ref_off.astype(np.int64), ref_len.astype(np.int64)
 
 
-@pytest.mark.parametrize("nb,layout", [(64, None), (4096, None), (24000, None), (24000, "ring")])
-def test_batch_calls_replay_from_a_graph_with_the_oracles_bytes(nb, layout, monkeypatch):
-    monkeypatch.setenv("SNAPPIER_HIP_TABLE_TRIES", "1")                       # (24 000 fragments: the lane compressor, a 1.6 GB workspace, no placement search in a test)
-    if layout:
-        monkeypatch.setenv("SNAPPIER_HIP_DECODE", layout)
+@pytest.mark.parametrize("nb,layout", [(64, None), (4096, None), (24000, None), (24000, "small")])
+def test_batch_calls_replay_from_a_graph_with_the_oracles_bytes(nb, layout):
     html = read_testdata("html")
     variant = O.HASH_CRC32C
     cd = SB.BlockCodec(0, variant)
+    cd.ctx.set_option(N.OPT_TABLE_PROBE_TRIES, 1)                             # (24 000 fragments: the lane compressor, a 1.6 GB workspace, no placement search in a test)
+    if layout:                                                                # the pre-pass + list kernels captured too
+        import layouts
+        layouts.set_decode_layout(cd.ctx, layout, small_max=512)
     raw = SD.html_like_blocks(html, 0, nb, "cuda")
     other = SD.html_like_blocks(html, 5 * nb, nb, "cuda")                     # different contents, same shape
     in_off, in_len = cd.uniform_layout(nb)

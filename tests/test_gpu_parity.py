@@ -13,6 +13,7 @@ import oracle as O
 from conftest import CORPUS, GOLDEN, ROOT, read_testdata
 import datagen
 import kats
+import layouts
 
 pytestmark = pytest.mark.gpu
 
@@ -378,22 +379,15 @@ def test_decompress_batch_per_block_status(codec):
     assert out[:65536].cpu().numpy().tobytes() == read_testdata("html")[:65536]
 
 
-@pytest.mark.parametrize("layout", ["win", "win-np2", "wing", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31", "lanes-opts87-slots1", "lanes-opts215-slots1", "lanes-opts151-slots2"])
-def test_compress_layouts_are_bit_identical(layout, monkeypatch):
-    """Both compressor layouts (one fragment per wavefront with the table in LDS -- the window kernel; one fragment per lane with the table
-    in an HBM workspace) must give the oracle's bytes on every kind of input, ragged lengths included."""
-    monkeypatch.setenv("SNAPPIER_HIP_COMPRESS", layout.split("-")[0])
-    if layout == "win-np2":             # window compressor with two positions per lane (default one)
-        monkeypatch.setenv("SNAPPIER_HIP_WIN_NP", "2")
-    if layout.endswith("-exact"):       # short literals stored with exact-length stores instead of one 16-byte store
-        monkeypatch.setenv("SNAPPIER_HIP_EXACT_LITERALS", "1")
-    if "-opts" in layout:               # lane kernel with another set of options (7 = no LDS staging; + 64 probe + insert as one atomic exchange,
-        monkeypatch.setenv("SNAPPIER_HIP_CL_OPTS", layout.split("-opts")[1].split("-")[0])   # + 128 input register window: what >= 131 072-fragment launches run)
-    if "-slots" in layout:              # probes per trip (the exchange acts with one only; batches this small default to two)
-        monkeypatch.setenv("SNAPPIER_HIP_CL_SLOTS", layout.split("-slots")[1])
+@pytest.mark.parametrize("layout", layouts.COMPRESS_LAYOUTS)
+def test_compress_layouts_are_bit_identical(layout):
+    """Both compressor layouts (one fragment per wavefront with the table in LDS or in a global slot -- the window kernel; one fragment per lane
+    with the table in an HBM workspace, under every store / probe option) must give the oracle's bytes on every kind of input, ragged lengths
+    included.  Selected through snp_ctx_set_option on the product library."""
     html = read_testdata("html")
     for variant in VARIANTS:
         cd = SB.BlockCodec(0, variant)
+        layouts.set_compress_layout(cd.ctx, layout)
         nb = 300
         for raw in (SD.html_like_blocks(html, 11, nb, "cuda"), SD.low_entropy_blocks(3, nb, "cuda"),
                     SD.corpus_blocks([read_testdata(n) for n in CORPUS], 2, nb, SD.MIXED_SEED, "cuda")):
@@ -411,24 +405,18 @@ def test_compress_layouts_are_bit_identical(layout, monkeypatch):
                         O.compress(html[in_off[b]:in_off[b] + n], variant))
         # whole files through the host API (multi-fragment)
         for name in ("html_x_4", "kppkn.gtb", "fireworks.jpeg"):
-            assert_same(f"{layout} {name}", Snappy.CompressToArray(read_testdata(name), S.Context(0, variant)),
+            assert_same(f"{layout} {name}", Snappy.CompressToArray(read_testdata(name), layouts.set_compress_layout(S.Context(0, variant), layout)),
                         O.compress(read_testdata(name), variant))
 
 
-@pytest.mark.parametrize("decode", ["queued", "chains", "ring", "batched", "serial", "small"])
+@pytest.mark.parametrize("decode", ["chains", "wave-only", "serial", "small", "small-grid"])
 @pytest.mark.parametrize("fenced", ["0", "1"])
-def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
+def test_decode_kernel_variants_agree(fenced, decode):
     """Same-wave store->load ordering: the default kernel relies on in-order vector memory; the fenced variant drains
-    vmcnt before touching young output.  The token-parallel front end and the serial loop must also agree.  All four
-    kernel variants must be exact on the overlap-heavy config, the html-like config and the mixed corpus."""
-    monkeypatch.setenv("SNAPPIER_HIP_FENCED", fenced)
-    if decode == "small":       # block-per-lane kernel first, for every block size; what it cannot finish goes to the wave kernel
-        monkeypatch.setenv("SNAPPIER_HIP_SMALL_MIN", "1")
-        monkeypatch.setenv("SNAPPIER_HIP_SMALL_MAX", "65536")
-        monkeypatch.setenv("SNAPPIER_HIP_REDO", "list")           # always the pre-pass + list kernel, whatever the previous batch was like
-    else:
-        monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
+    vmcnt before touching young output.  The token-parallel front end, the small-block pre-pass with its two leftover forms and the serial
+    loop must also agree.  Every variant must be exact on the overlap-heavy config, the html-like config and the mixed corpus."""
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    layouts.set_decode_layout(cd.ctx, decode, fenced)
     nb = 512
     _roundtrip_blocks(cd, SD.low_entropy_blocks(1000, nb, "cuda"), nb, O.HASH_CRC32C, 128)
     _roundtrip_blocks(cd, SD.html_like_blocks(read_testdata("html"), 77, nb, "cuda"), nb, O.HASH_CRC32C, 128)
@@ -451,8 +439,8 @@ def test_decode_kernel_variants_agree(fenced, decode, monkeypatch):
     assert dst.cpu().tolist() == [O.decompress_status(b, c) for b, c in zip(blobs, caps)]
 
 
-@pytest.mark.parametrize("decode", ["chains", "ring", "queued", "batched", "serial"])
-def test_streams_built_against_the_sub_chain_decoder(decode, monkeypatch):
+@pytest.mark.parametrize("decode", ["chains", "wave-only", "serial", "small"])
+def test_streams_built_against_the_sub_chain_decoder(decode):
     """Legal Snappy that no 64 KiB-fragment compressor emits, chosen so that the guessed chains of the sub-chain front end
     (decompress.hip, FRONT = 3) rarely or never land on a tag start: 5- and 7-byte tag periods, literal bodies made of
     long-literal tag bytes, copy-2 offsets that read as long literals.  Output and status must equal the oracle's through
@@ -461,8 +449,8 @@ def test_streams_built_against_the_sub_chain_decoder(decode, monkeypatch):
     spec = importlib.util.spec_from_file_location("adversarial_streams", os.path.join(ROOT, "scripts", "adversarial_streams.py"))
     A = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(A)
-    monkeypatch.setenv("SNAPPIER_HIP_DECODE", decode)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    layouts.set_decode_layout(cd.ctx, decode)
     blobs, caps = [], []
     for kind in A.KINDS:
         s = A.build(kind)
@@ -814,13 +802,13 @@ def test_frame_decode_device_walks_the_headers_itself(codec):
 
 
 @pytest.mark.parametrize("scan", ["spans", "serial"])
-def test_frame_decode_device_span_walk(scan, monkeypatch):
+def test_frame_decode_device_span_walk(scan):
     """The concurrent header walk (frame_scan.hip: 1 MiB spans, candidate entry points, resolver, emitter) against the
     oracle and against the one-lane walk on streams built to hit its corners: chunks straddling span boundaries, a
     skippable chunk larger than several spans, raw payloads full of fake chunk headers, hundreds of tiny chunks (more
     candidates than a span keeps), errors deep in the stream, a full chunk table, a short output buffer."""
-    monkeypatch.setenv("SNAPPIER_HIP_FRAME_SCAN", scan)
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
+    cd.ctx.set_option(N.OPT_FRAME_SCAN, 1 if scan == "serial" else 0)
     rng = np.random.default_rng(2)
 
     def chunk(t, body):
@@ -892,7 +880,7 @@ def test_frame_decode_device_span_walk(scan, monkeypatch):
 # ------------------------------------------------------------------ full BASELINE size, size-independent properties
 
 @pytest.mark.timeout(1200)
-def test_full_size_config2_roundtrip(codec, monkeypatch):
+def test_full_size_config2_roundtrip(codec):
     """10 GiB of 64 KiB html-like blocks (BASELINE.json configs[1]): decode(encode(x)) == x for every block, every
     status OK, every decoded length 65536, and EVERY one of the 163 840 compressed blocks equals the oracle's (length + CRC-32C of
     the bytes; byte compare on any mismatch) -- through the default context (16-piece workspace, input register window, non-temporal
@@ -909,15 +897,15 @@ def test_full_size_config2_roundtrip(codec, monkeypatch):
     assert bool((dlen == 65536).all())
     assert torch.equal(back, raw)
     assert _oracle_all(cd, raw, out, out_off, out_len, nb, O.HASH_CRC32C, "default context") == nb
-    # the same 10 GiB through the output-granular decoder (FRONT = 4, SNAPPIER_HIP_DECODE=ring: not the default, kept as a measured alternative)
-    monkeypatch.setenv("SNAPPIER_HIP_DECODE", "ring")
-    ringc = SB.BlockCodec(0, O.HASH_CRC32C)
+    # the same 10 GiB with the pre-pass pinned (every block is offered to decompress_small.hip first, all of them come back through the list kernel)
+    listc = SB.BlockCodec(0, O.HASH_CRC32C)
+    layouts.set_decode_layout(listc.ctx, "small", small_max=512)
     back.zero_()
-    dlen, dst = ringc.decompress(out, out_off, out_len, back, in_off, in_len)
+    dlen, dst = listc.decompress(out, out_off, out_len, back, in_off, in_len)
     torch.cuda.synchronize()
     assert int((dst != 0).sum()) == 0 and bool((dlen == 65536).all()) and torch.equal(back, raw)
-    monkeypatch.delenv("SNAPPIER_HIP_DECODE")
-    del ringc
+    listc.ctx.close()
+    del listc
     out2, _oo, out_len2, _st = cd.compress(raw, in_off, in_len, out=torch.empty_like(out))
     torch.cuda.synchronize()
     assert torch.equal(out_len, out_len2)
