@@ -241,6 +241,8 @@ def cpu_baseline(raw_sample: np.ndarray, variant: int):
     return {
         "value": value, "unit": "GB/s uncompressed, compress+decompress round trip",
         "cores": used, "host_cpus": ncpu, "cpu_model": cpu_model(), "kind": "port",
+        "range_seen": "11-21 GB/s across the processes of rounds 4-6 on this host model (a shared 256-thread host: the same build moves by 2 x between processes); "
+                      "the value is a per-leg maximum over thread counts, which flatters the CPU slightly -- a stated baseline, never the target",
         "compress_GBps": best_c[0], "compress_leg": best_c[1], "decompress_GBps": best_d[0], "decompress_leg": best_d[1],
         "legs": {"oracle": plain, "oracle_fast": fast, "libsnappy": snappy},
         "crc32c_GBps": crc,
@@ -250,6 +252,38 @@ def cpu_baseline(raw_sample: np.ndarray, variant: int):
                 "moves literals and self-copies 16 bytes at a time as Snappier's SIMD path does (CopyHelpers.cs:64-230), and C++ snappy's decoder is the "
                 "code Snappier's is a port of: the best of these is the closest this host gets to Snappier's own speed",
     }
+
+
+def sclk_reader(dev_index: int):
+    """-> a function that reads this GPU's current shader clock in MHz from sysfs (hwmon freq1_input of the PCI device torch reports: one
+    file read, ~50 us -- rocm-smi takes 80 ms, longer than the launches it would sample), or None when the host does not expose it."""
+    import glob
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        base = f"/sys/bus/pci/devices/{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        files = glob.glob(os.path.join(base, "hwmon", "hwmon*", "freq1_input"))
+        if not files:
+            return None
+        path = files[0]
+
+        def level(name):                                        # the line pp_dpm_<name> marks with '*': the current level of that clock domain
+            try:
+                with open(os.path.join(base, name)) as f:
+                    for line in f:
+                        if "*" in line:
+                            return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+            except (OSError, ValueError, IndexError):
+                pass
+            return None
+
+        def read():
+            with open(path) as f:
+                sclk = round(int(f.read().strip()) / 1e6)
+            return {"sclk": sclk, "mclk": level("pp_dpm_mclk"), "fclk": level("pp_dpm_fclk")}
+        read()
+        return read
+    except Exception:                                           # noqa: BLE001
+        return None
 
 
 def pmc_rows(directory: str, counter: str) -> dict:
@@ -328,6 +362,9 @@ def main():
     ap.add_argument("--config5-lines", action="store_true",
                     help="after the measured workload, also run configs[4] (mixed corpus, block-sharded) and report config5_lines; "
                          "on by default when --gpus > 1")
+    ap.add_argument("--thorough-search", action="store_true",
+                    help="build the hash-table workspace with the thorough placement search (SNP_OPT_TABLE_PROBE_TRIES = 24, up to 3/4 of device memory, seconds) "
+                         "instead of the library's bounded default; `value` then says so in config.workspace")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip `other_configs` (N = 1 only: BASELINE configs[2], configs[3] and the configs[4] share, 3 steps each, and the CRC kernel; ~15 s)")
     args = ap.parse_args()
@@ -377,13 +414,16 @@ def main():
     with open(os.path.join(td, "html"), "rb") as f:
         html = f.read()
     cd = SB.BlockCodec(local_rank, variant)
+    thorough = args.thorough_search or bool(os.environ.get("BENCH_TABLE_TRIES"))
     if not os.environ.get("BENCH_NO_RESERVE"):
-        # what a service does at start-up: the device's hash-table workspace is built before the buffers exist, so the placement
-        # search sees all of device memory -- and the THOROUGH search is asked for explicitly (the library's default holds two
-        # workspaces' worth of candidates at most; what that default is worth is measured below as value_default_search).  Untimed either way.
-        from snappier_amd import _native as N0
-        cd.ctx.set_option(N0.OPT_TABLE_PROBE_TRIES, int(os.environ.get("BENCH_TABLE_TRIES", "24")))
-        cd.ctx.set_option(N0.OPT_TABLE_PROBE_MAX_BYTES, int(free // 4 * 3))        # (the third kind of device memory has been seen to begin beyond the first half)
+        # what a service does at start-up: the device's hash-table workspace is built before the buffers exist.  With the library's
+        # DEFAULT options (round 6: this is what produces `value`): the bounded placement search -- at most two workspaces' worth of candidate pieces,
+        # never more than half of free memory, < 1 s.  --thorough-search asks for the 24-workspace search instead (seconds, up to 3/4 of device memory:
+        # worth 0-5 % depending on where the driver placed things).  Untimed either way; its cost is `workspace_search`.
+        if thorough:
+            from snappier_amd import _native as N0
+            cd.ctx.set_option(N0.OPT_TABLE_PROBE_TRIES, int(os.environ.get("BENCH_TABLE_TRIES", "24")))
+            cd.ctx.set_option(N0.OPT_TABLE_PROBE_MAX_BYTES, int(free // 4 * 3))        # (the third kind of device memory has been seen to begin beyond the first half)
         cd.ctx.reserve_compress(nb)
 
     def make_blocks(kind: int):
@@ -459,6 +499,51 @@ def main():
     ms_d = float(np.mean([a.elapsed_time(b) for a, b in t_dec]))
     cpu_sample = raw[: min(args.cpu_sample_blocks, nb) * BLOCK].cpu().numpy() if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
 
+    # ---- the decoder ALONE and the shader clock around the launches: inside the step the decode launch follows a ~96 ms compress
+    # launch that is bound by memory latency, and runs 5-9 % slower than in a loop of its own.  Decode-only launches back to back (events), and
+    # the clock sampled from sysfs while each kind of launch runs and right after it (host-side sampling of a free-running clock: indicative).
+    alone = None
+    if world == 1:
+        rd = sclk_reader(local_rank)
+        def sample_during(fn, wait_s):
+            """launch fn (asynchronous), read the clock wait_s later (the launch is still running), then right after it has finished"""
+            torch.cuda.synchronize()
+            fn()
+            time.sleep(wait_s)
+            during = rd() if rd else None
+            torch.cuda.synchronize()
+            after = rd() if rd else None
+            return during, after
+        a_ev = []
+        torch.cuda.synchronize()
+        for _ in range(6):
+            e0, e1 = ev(), ev()
+            e0.record()
+            dl_a, ds_a = cd.decompress(comp, comp_off, out_len, back, in_off, in_len)
+            e1.record()
+            a_ev.append((e0, e1))
+        torch.cuda.synchronize()
+        a_ms = [a.elapsed_time(b) for a, b in a_ev]
+        clk = {}
+        if rd:
+            clk["idle_before"] = rd()
+            clk["during_compress"], clk["after_compress"] = sample_during(lambda: cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off), ms_c * 0.6e-3)
+            def comp_then_dec():
+                _o, _oo, ol_, _s = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
+                cd.decompress(comp, comp_off, ol_, back, in_off, in_len)
+            clk["during_decode_in_step"], clk["after_decode_in_step"] = sample_during(comp_then_dec, (ms_c + ms_d * 0.5) * 1e-3)
+            def dec4():
+                for _ in range(4):
+                    cd.decompress(comp, comp_off, out_len, back, in_off, in_len)
+            clk["during_decode_alone"], clk["after_decode_alone"] = sample_during(dec4, ms_d * 3.5e-3)
+        if not (int((ds_a != 0).sum()) == 0 and torch.equal(back, raw)):
+            sys.exit("[bench] decode-alone round trip is NOT bit-exact")
+        alone = {"decompress_ms_alone": round(float(np.mean(a_ms[1:])), 3), "launches_ms": [round(x, 3) for x in a_ms],
+                 "how": "six decode-only launches back to back after the timed steps (HIP events on the launch stream; the first follows idle time and is left out of the mean)",
+                 "clocks_mhz": clk or "not readable on this host (no hwmon freq1_input for the device)",
+                 "clocks_how": "shader clock (sysfs hwmon freq1_input) and the current memory / fabric clock levels (pp_dpm_mclk, pp_dpm_fclk) of this GPU, read from the host while the launch runs (60 % into a compress launch; half way into the decode launch "
+                             "that follows a compress launch; during the fourth of four back-to-back decode launches) and right after it finished"}
+
     # ---- what the placement search is worth: the same kernels on a PLAIN one-allocation workspace (second context, SNP_OPT_TABLE_PROBE_TRIES = 1) ----
     lanes = nb >= 16384
     search = {"candidates": int(S.lib().snp_ctx_counter(cd.ctx.handle, 3)), "transient_bytes": int(S.lib().snp_ctx_counter(cd.ctx.handle, 5)),
@@ -497,7 +582,7 @@ def main():
         del cd2
     # ---- what the library's DEFAULT options give: a fresh pool (every context of this process is gone), no option set, no reserve call -------
     default_search = None
-    if lanes and world == 1 and not os.environ.get("BENCH_NO_DEFAULT_SEARCH"):
+    if lanes and world == 1 and thorough and not os.environ.get("BENCH_NO_DEFAULT_SEARCH"):
         import gc
         from snappier_amd import batch as SB2
         comp_stride = cd.comp_stride
@@ -693,6 +778,9 @@ def main():
                     "uncompressed_GBps": round(u_bytes / (ms * 1e-3) / 1e9, 2)}
         r_c = roof(ms_c, "k_compress_lanes" if lanes else "k_compress_win")
         r_d = roof(ms_d, "k_decode_chains")
+        if alone:
+            r_d.update(alone)
+            r_d["frac_alone"] = round(alg / (alone["decompress_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
         if lanes:
             r_c["table_workspace_probe"] = {"chosen_ms": search["chosen_set_probe_ms"], "candidates": search["candidates"]}
         if lanes and args.config == 2:
@@ -722,7 +810,11 @@ def main():
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
                        "layout": "decompress: one block per wavefront (k_decode_chains: sub-chain tag parse over 2 KiB super-windows through an LDS table of tag advances, 64 tags per execution batch staged in LDS); compress: one fragment per lane, hash tables in an HBM workspace of 16 pieces spread over the kinds of device memory, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
-                       "workspace": "the device's hash-table workspace built by snp_ctx_reserve_compress before the buffers are allocated, with the THOROUGH placement search asked for explicitly (SNP_OPT_TABLE_PROBE_TRIES = 24; a service's start-up: untimed, like the setup pass; its cost is workspace_search, what the default bounded search gives is value_default_search)" if not os.environ.get("BENCH_NO_RESERVE") else "hash-table workspace built by the untimed setup pass",
+                       "workspace": ("hash-table workspace built by the untimed setup pass" if os.environ.get("BENCH_NO_RESERVE") else
+                                     "the device's hash-table workspace built by snp_ctx_reserve_compress before the buffers are allocated (a service's start-up: untimed, like the setup pass; its cost is workspace_search), " +
+                                     ("with the THOROUGH placement search asked for explicitly (--thorough-search: SNP_OPT_TABLE_PROBE_TRIES = 24; what the default bounded search gives is value_default_search)" if thorough else
+                                      "LIBRARY DEFAULT options: the bounded placement search (<= two workspaces' worth of candidates, <= half of free memory)")),
+                       "value_range_seen": "placement of the 10.7 GB of hash tables decides +-8 % of the compressor's rate (random read-modify-writes: where hipMalloc landed, DESIGN 4.3/7.3): round 5 boxes 86.9-101.6 GB/s (plain 81.0-90.1, default search 91.9-101.2, thorough 96.0-101.6); round 6: see DESIGN 10",
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,

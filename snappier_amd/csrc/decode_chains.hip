@@ -30,13 +30,18 @@
 //     stage   NEAR copies of the new batch (source inside the held batch or the history) read their pieces from the stage; the last 64
 //             bytes of what the stage holds move below its first byte (the new batch's history); every piece is stored; the new batch
 //             is now the held one.
-//   Nothing is held across a super-window build (it uses the stage as scratch), a literal > 64 bytes (copied by the whole wave) or an exit.
-//   A batch ends before the first tag it cannot take (malformed, a literal > 64 bytes, the last 16 output bytes); anything irregular falls
+//   A literal of 65..128 bytes takes TWO slots of a batch (its first 64 bytes, the rest).  Nothing is held across a super-window build (it uses
+//   the stage as scratch), a literal > 128 bytes (copied by the whole wave) or an exit.
+//   A batch ends before the first tag it cannot take (malformed, a literal > 128 bytes, the last 16 output bytes); anything irregular falls
 //   to serial_tail(), which owns the reference's error semantics.
 #include "decode_common.h"
 
 // Phase markers for scripts/isa_budget.py (comments in the assembly: no instructions, no barriers beyond `volatile`).
 #define SNP_MARK(name) asm volatile("; MARK " #name)
+
+#ifndef SNP_DC_FINISH_MIN
+#define SNP_DC_FINISH_MIN 1      // the in-order finish without an EXEC mask (round 6: html 9.25 -> 9.02 ms per 10 GiB, same-process A/B, profiles/r06a_ab_decode.jsonl); 0 = the round-5 loop
+#endif
 
 namespace {
 
@@ -152,6 +157,8 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
         if (h_pend) {
             if (FENCED && fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the slow form reads global memory)
             const u32 vbase = lane + static_cast<u32>(reinterpret_cast<uintptr_t>(c_stage));   // LDS address of this lane's byte of a tag at stage offset 0
+            const u32 vbase0 = vbase - lane;
+            (void)vbase0;
             u64 pend = h_pend;
             while (pend) {
                 u32 f, k;
@@ -159,6 +166,35 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
                 // kernel, measured).  Pops tags off `pend` until it is empty or the popped tag (f, k < 0) needs the slow form below.  EXEC
                 // is restored before the block ends; the LDS operations of a wavefront execute in order, so a tag reads what the tag
                 // before it wrote.
+#if SNP_DC_FINISH_MIN
+                // No EXEC mask: lanes at or beyond the tag's length repeat the copy of its LAST byte (same source, same destination, same value):
+                // v_min replaces v_cmp + s_and_saveexec + s_mov exec -- 16 instructions per tag, 9 of them scalar.  (k carries len - 1 here.)
+                {
+                    u32 t0, t1, t2, va, vb, vi;
+                    asm volatile(
+                        "1:\n\t"
+                        "s_ff1_i32_b64 %[f], %[pend]\n\t"
+                        "v_readlane_b32 %[k], %[pk], %[f]\n\t"
+                        "s_bitset0_b64 %[pend], %[f]\n\t"
+                        "s_cmp_lt_i32 %[k], 0\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_bfe_u32 %[t0], %[k], 0x7000b\n\t"
+                        "s_lshr_b32 %[t1], %[k], 18\n\t"
+                        "s_and_b32 %[t2], %[k], 0x7ff\n\t"
+                        "v_min_u32_e32 %[vi], %[t0], %[lane]\n\t"
+                        "v_add3_u32 %[va], %[vi], %[t1], %[vsrc]\n\t"
+                        "ds_read_u8 %[vb], %[va]\n\t"
+                        "v_add3_u32 %[va], %[vi], %[t2], %[vbase]\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "ds_write_b8 %[va], %[vb]\n\t"
+                        "s_cmp_lg_u64 %[pend], 0\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "2:"
+                        : [pend] "+s"(pend), [f] "=&s"(f), [k] "=&s"(k), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2),
+                          [va] "=&v"(va), [vb] "=&v"(vb), [vi] "=&v"(vi)
+                        : [pk] "v"(h_pk), [lane] "v"(lane), [vbase] "v"(vbase0), [vsrc] "v"(vbase0 - kHist)
+                        : "scc", "memory");
+#else
                 {
                     u32 t0, t1, t2, va, vb;
                     u64 sv;
@@ -187,10 +223,11 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
                           [va] "=&v"(va), [vb] "=&v"(vb)
                         : [pk] "v"(h_pk), [lane] "v"(lane), [vbase] "v"(vbase), [vsrc] "v"(vbase - kHist)
                         : "vcc", "scc", "memory");
+#endif
                     if (static_cast<i32>(k) >= 0) break;            // (pend is empty)
                 }
                 // the slow form: a pattern copy (off < len: CopyHelpers.cs:222-230 copies byte by byte), or a source that starts below the batch
-                const u32 f_d = k & 0x7ffu, f_len = (k >> 11) & 0x7fu;
+                const u32 f_d = k & 0x7ffu, f_len = ((k >> 11) & 0x7fu) + (SNP_DC_FINISH_MIN ? 1u : 0u);
                 const u32 f_off = (k >> 18) & 0x1fffu;
                 const u32 sidx = f_off < f_len ? lane_mod(lane, f_off) : lane;
                 const u32 spos = f_d + sidx - f_off;                // from the batch's first byte; wraps when below it
@@ -516,13 +553,16 @@ SNP_MARK(B_stage);
             const u8 hb = c_stage[static_cast<i32>(gap + lane - kHist)];
             if (lane >= kHist - hist) c_stage[static_cast<i32>(lane - kHist)] = hb;
         }
+        // (the near pieces and the history byte above are READ from the stage bytes the stores below overwrite, through differently typed unaligned
+        //  accesses: the compiler must not move a store above them -- the hardware keeps a wavefront's DS operations in order: ADVICE r5)
+        lanes_sync_lds();
         if (early | near) store_pieces(c_stage + drel, len, any_mid, p0, p1, p2, p3);
         {
             // The rest waits for the next trip, in order, whole wave per tag, a byte per lane.  One packed word per tag (v_readlane): destination,
             // length, and either the source inside the stage or a flag for the slow form (pattern copy, source that starts below the batch).
             const bool plain = (off >= len) & (off <= drel + hist);     // not a pattern copy, source inside the batch or the history below it
             h_pend = ballot64(waits);
-            h_pk = drel | (len << 11) | (plain ? (drel - off + kHist) << 18 : 0x80000000u | (off << 18));   // (plain: the source, counted from the
+            h_pk = drel | ((len - (SNP_DC_FINISH_MIN ? 1u : 0u)) << 11) | (plain ? (drel - off + kHist) << 18 : 0x80000000u | (off << 18));   // (plain: the source, counted from the
                                                                         //  history's first byte; slow: the offset -- a waiting tag's is < drel + len + 64)
             h_op = op;
             h_span = span;
