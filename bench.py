@@ -545,7 +545,7 @@ def main():
                              "that follows a compress launch; during the fourth of four back-to-back decode launches) and right after it finished"}
 
     # ---- what the placement search is worth: the same kernels on a PLAIN one-allocation workspace (second context, SNP_OPT_TABLE_PROBE_TRIES = 1) ----
-    lanes = nb >= 16384
+    lanes = nb >= 32768                                        # (layout 0: the lane compressor from 32 768 fragments on)
     search = {"candidates": int(S.lib().snp_ctx_counter(cd.ctx.handle, 3)), "transient_bytes": int(S.lib().snp_ctx_counter(cd.ctx.handle, 5)),
               "seconds": round(S.lib().snp_ctx_counter(cd.ctx.handle, 4) / 1e6, 3), "chosen_set_probe_ms": S.lib().snp_ctx_counter(cd.ctx.handle, 2) / 1e3,
               "where": "snp_ctx_reserve_compress before the buffers exist (untimed start-up work)" if not os.environ.get("BENCH_NO_RESERVE") else "first compress call (untimed setup pass)"}
@@ -809,7 +809,7 @@ def main():
                                    (f"REDUCED from {reduced_from} blocks (device memory short), " if reduced_from else "") +
                                    "step = compress all + decompress all (+ RCCL length/status gather when N > 1)",
                        "blocks_per_gpu": nb, "block_bytes": BLOCK, "hash_variant": args.hash,
-                       "layout": "decompress: one block per wavefront (k_decode_chains: sub-chain tag parse over 2 KiB super-windows through an LDS table of tag advances, 64 tags per execution batch staged in LDS); compress: one fragment per lane, hash tables in an HBM workspace of 16 pieces spread over the kinds of device memory, probe + insert as one atomic exchange (>= 16384 fragments), else one per wavefront with the table in LDS",
+                       "layout": "decompress: one block per wavefront (k_decode_chains: sub-chain tag parse over 2 KiB super-windows through an LDS table of tag advances, 64 tags per execution batch staged in LDS); compress: one fragment per lane, hash tables in an HBM workspace of 16 pieces spread over the kinds of device memory, probe + insert as one atomic exchange (>= 32768 fragments), else one per wavefront: table in LDS, from 4096 fragments joined by a second population with cache-resident global table slots",
                        "workspace": ("hash-table workspace built by the untimed setup pass" if os.environ.get("BENCH_NO_RESERVE") else
                                      "the device's hash-table workspace built by snp_ctx_reserve_compress before the buffers are allocated (a service's start-up: untimed, like the setup pass; its cost is workspace_search), " +
                                      ("with the THOROUGH placement search asked for explicitly (--thorough-search: SNP_OPT_TABLE_PROBE_TRIES = 24; what the default bounded search gives is value_default_search)" if thorough else

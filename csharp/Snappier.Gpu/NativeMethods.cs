@@ -28,7 +28,7 @@ public enum SnpOption : int
     DecodeLayout = 1,           // 0 by the previous batch, 1 one block per wavefront, 2 a lane per small block, 3/4/5 a team of 4/8/16 lanes, 6 the serial kernel
     SmallBlockMax = 2,
     SmallBlockMinBatch = 3,
-    CompressLayout = 4,         // 0 by batch size, 2 fragment per lane (HBM tables), 3 fragment per wavefront (LDS table), 4 the same with the table in a global-memory slot
+    CompressLayout = 4,         // 0 by batch size, 2 fragment per lane (HBM tables), 3 fragment per wavefront (LDS table), 4 the same with the table in a global-memory slot, 5 both table forms side by side
     CompressWindowMaxBatch = 5,
     TableProbeTries = 6,        // workspaces' worth of candidate pieces the DEVICE's hash-table workspace search may hold (default 2; 3..24 = the thorough search, 1 = a plain workspace of the context's own)
     TableProbeMaxBytes = 7,     // cap on the transient footprint of that search (default: half of free memory; an explicit cap is honoured up to 7/8)
@@ -47,6 +47,8 @@ public enum SnpOption : int
     CompressSmallInputLanes = 19,
     FrameScan = 20,
     DecodeLdsThrottle = 21,
+    CompressWindowGlobalSlots = 22,
+    CompressWindowDualMinBatch = 23,
 }
 
 /// <summary>Names this binding used before round 5 (same numbers).</summary>

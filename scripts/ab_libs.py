@@ -28,6 +28,8 @@ def codec_of(path):
     cd = SB.BlockCodec(0, S.HASH_CRC32C)
     if layout:
         layouts.set_compress_layout(cd.ctx, layout)
+    if os.environ.get("SLOTS"):
+        cd.ctx.set_option(N.OPT_COMPRESS_WINDOW_GLOBAL_SLOTS, int(os.environ["SLOTS"]))
     return cd
 
 cds = [(p, codec_of(p)) for p in libs]

@@ -27,11 +27,11 @@ MAX_BLOCK_COMPRESSED = 76491
  OPT_TABLE_PROBE_TRIES, OPT_TABLE_PROBE_MAX_BYTES, OPT_PARALLEL_DECODE_MIN, OPT_FENCED, OPT_DECODE_LEFTOVERS, OPT_CRC_KERNEL,
  OPT_COMPRESS_WINDOW_POSITIONS, OPT_COMPRESS_WINDOW_GLOBAL_MIN_BATCH, OPT_COMPRESS_LANE_STORES, OPT_COMPRESS_LANE_PROBES,
  OPT_COMPRESS_LANES_PER_WAVEFRONT, OPT_COMPRESS_SLICE, OPT_COMPRESS_SMALL_INPUT_LDS, OPT_COMPRESS_SMALL_INPUT_LANES, OPT_FRAME_SCAN,
- OPT_DECODE_LDS_THROTTLE) = range(1, 22)
+ OPT_DECODE_LDS_THROTTLE, OPT_COMPRESS_WINDOW_GLOBAL_SLOTS, OPT_COMPRESS_WINDOW_DUAL_MIN_BATCH) = range(1, 24)
 OPT_CRC_TABLE_FREE = OPT_CRC_KERNEL     # deprecated name (rounds 1-4), same number
 # SNP_OPT_DECODE_LAYOUT / SNP_OPT_COMPRESS_LAYOUT values
 DECODE_AUTO, DECODE_WAVE_ONLY, DECODE_SMALL_LANES, DECODE_SMALL_TEAM4, DECODE_SMALL_TEAM8, DECODE_SMALL_TEAM16, DECODE_SERIAL = range(7)
-COMPRESS_AUTO, COMPRESS_LANES, COMPRESS_WINDOW_LDS, COMPRESS_WINDOW_GLOBAL = 0, 2, 3, 4
+COMPRESS_AUTO, COMPRESS_LANES, COMPRESS_WINDOW_LDS, COMPRESS_WINDOW_GLOBAL, COMPRESS_WINDOW_DUAL = 0, 2, 3, 4, 5
 
 
 def declared_symbols() -> list[str]:

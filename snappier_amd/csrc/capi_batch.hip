@@ -133,13 +133,24 @@ bool snp_ctx::launch_compress(const u8* d_in, const u64* in_off, const u32* in_l
     // tables) needs >= 16 384 fragments in flight before its memory-level parallelism overtakes it.
     // ... and between the two, from win_gtab_min fragments on, the window kernel keeps its u16 tables in a 256 MiB global-memory workspace that
     // stays in L2 / Infinity Cache instead of in LDS (compress_win.hip, WinTable): 32 wavefronts per CU instead of 4.
-    const bool win = compress_mode == 3 || compress_mode == 4 || (compress_mode == 0 && nblocks < win_max);
+    const bool win = compress_mode == 3 || compress_mode == 4 || compress_mode == 5 || (compress_mode == 0 && nblocks < win_max);
     if (win) {
+        // ... and from win_dual_min fragments on BOTH forms at once, on two streams, drawing fragments from one ticket counter (compress_win.hip, dual form:
+        // 45-47 GB/s against 34.5 / 36.5 for either alone).  A context whose side stream cannot be created (or a first use under capture) keeps the single form.
+        if ((compress_mode == 5 || (compress_mode == 0 && nblocks >= win_dual_min)) && win_np == 1 && (side_state > 0 || (!stream_is_capturing() && side_stream_ready()))) {
+            const u32 per_cu = persistent_waves() / 32u;                 // (= CUs)
+            u32 slots = win_gslots ? win_gslots : per_cu * 10u;
+            if (nblocks < slots) slots = nblocks;
+            if (!ensure(win_tables, snp_compress_win_table_bytes(slots), "hipMalloc(window tables)") || !ensure(small, 256, "hipMalloc(scalars)")) return false;
+            return check(snp_launch_compress_win_dual(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant, emit_varint, stream, side_stream,
+                                                      side_ev[0], side_ev[1], static_cast<uint16_t*>(win_tables.p), slots, per_cu * 4u,
+                                                      static_cast<u32*>(small.p) + 16), "compress (windows, dual) launch");
+        }
         const bool gtab = compress_mode == 4 || (compress_mode == 0 && nblocks >= win_gtab_min);
         uint16_t* tabs = nullptr;
         u32 slots = 0;
         if (gtab) {
-            slots = persistent_waves();
+            slots = win_gslots ? win_gslots : persistent_waves() / 32u * 12u;
             if (nblocks < slots) slots = nblocks;
             if (!ensure(win_tables, snp_compress_win_table_bytes(slots), "hipMalloc(window tables)")) return false;
             tabs = static_cast<uint16_t*>(win_tables.p);
@@ -188,6 +199,18 @@ bool snp_ctx::launch_compress(const u8* d_in, const u64* in_off, const u32* in_l
         else
             (void)hipGetLastError();
     }
+    return true;
+}
+
+bool snp_ctx::side_stream_ready()
+{
+    if (side_state) return side_state > 0;
+    side_state = -1;
+    RelaxedCaptureMode relaxed;
+    if (hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); side_stream = nullptr; return false; }
+    for (auto& e : side_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    side_state = 1;
     return true;
 }
 

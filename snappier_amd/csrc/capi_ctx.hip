@@ -190,7 +190,7 @@ snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
             c->small_min_blocks = static_cast<u32>(v);
             return SNP_OK;
         case SNP_OPT_COMPRESS_LAYOUT:
-            if (v != 0 && v != 2 && v != 3 && v != 4) return SNP_ERR_BAD_ARG;
+            if (v != 0 && v != 2 && v != 3 && v != 4 && v != 5) return SNP_ERR_BAD_ARG;
             c->compress_mode = static_cast<int>(v);
             return SNP_OK;
         case SNP_OPT_COMPRESS_WINDOW_MAX_BATCH:
@@ -259,6 +259,14 @@ snp_status snp_ctx_set_option(snp_ctx* c, int option, int64_t v)
             if (v != 0 && v != 1) return SNP_ERR_BAD_ARG;
             c->frame_scan = static_cast<int>(v);
             return SNP_OK;
+        case SNP_OPT_COMPRESS_WINDOW_GLOBAL_SLOTS:
+            if (v < 0 || v > 65536) return SNP_ERR_BAD_ARG;
+            c->win_gslots = static_cast<u32>(v);
+            return SNP_OK;
+        case SNP_OPT_COMPRESS_WINDOW_DUAL_MIN_BATCH:
+            if (v < 0 || v > 0xffffffffll) return SNP_ERR_BAD_ARG;
+            c->win_dual_min = static_cast<u32>(v);
+            return SNP_OK;
         case SNP_OPT_DECODE_LDS_THROTTLE:
             if (v < 0 || v > 65536) return SNP_ERR_BAD_ARG;
             c->dec_lds = static_cast<int>(v / 256 * 256);
@@ -293,6 +301,8 @@ snp_status snp_ctx_get_option(const snp_ctx* c, int option, int64_t* out)
         case SNP_OPT_COMPRESS_SMALL_INPUT_LANES: *out = c->lane_tune.small_lanes; return SNP_OK;
         case SNP_OPT_FRAME_SCAN: *out = c->frame_scan; return SNP_OK;
         case SNP_OPT_DECODE_LDS_THROTTLE: *out = c->dec_lds; return SNP_OK;
+        case SNP_OPT_COMPRESS_WINDOW_GLOBAL_SLOTS: *out = c->win_gslots; return SNP_OK;
+        case SNP_OPT_COMPRESS_WINDOW_DUAL_MIN_BATCH: *out = c->win_dual_min; return SNP_OK;
         default: return SNP_ERR_BAD_ARG;
     }
 }
@@ -316,6 +326,8 @@ void snp_ctx_destroy(snp_ctx* c)
         if (c->chint) (void)hipHostFree(c->chint);
         if (c->hint) (void)hipHostFree(c->hint);
         if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+        if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+        for (auto& e : c->side_ev) if (e) (void)hipEventDestroy(e);
         for (auto& e : c->copy_ev) if (e) (void)hipEventDestroy(e);
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
     }

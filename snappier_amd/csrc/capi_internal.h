@@ -39,6 +39,8 @@ hipError_t snp_launch_tag_index_finish(const u8*, u32, u32, u32, u64*, u64*, u32
 hipError_t snp_launch_compress_win(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, int,
                                    hipStream_t, uint16_t*, u32);
 size_t snp_compress_win_table_bytes(u32);
+hipError_t snp_launch_compress_win_dual(const u8*, const u64*, const u32*, u32, u8*, const u64*, u32*, i32*, int, int, hipStream_t, hipStream_t,
+                                        hipEvent_t, hipEvent_t, uint16_t*, u32, u32, u32*);
 hipError_t snp_launch_decompress_small(const u8*, const u64*, const u32*, u32, u8*, const u64*, const u32*, u32*, i32*, const u8*,
                                        u32, hipStream_t, u32*, u32*, u32, u32);
 hipError_t snp_launch_sample_caps(const u32*, u32, u32, u32*, hipStream_t);
@@ -137,8 +139,17 @@ struct snp_ctx {
     u32 slice_fragments = 262144;   // fragments per lane-compressor launch (SNP_OPT_COMPRESS_SLICE)
     u32 win_gtab_min = 4096; // auto mode: window-kernel batches of at least this many fragments keep their tables in global memory (SNP_OPT_COMPRESS_WINDOW_GLOBAL_MIN_BATCH):
                              // 36.5 vs 34.6 GB/s from 4 096 fragments up, 19.8 vs 35.5 at 1 024 (profiles/r05zz_compress_by_batch.jsonl)
-    u32 win_max = 20480;     // auto mode: batches below this many fragments take the window kernel (SNP_OPT_COMPRESS_WINDOW_MAX_BATCH): the lane kernel needs its
-                             // ~31-37 ms whatever the count up to ~20 000 fragments (16 384: 33.0 GB/s against the window kernel's 36.5; 20 480: 35.9 against 35.7; 32 768: 52.2 against 36.3)
+    u32 win_gslots = 0;      // global-slot window kernel: wavefronts (= 32 KiB table slots) it runs with; 0 = by the form: 12 per CU alone (3 072: 38.9-39.5 GB/s against 36.5 at 32 per CU,
+                             // whose slots thrash L2), 10 per CU beside the LDS form (SNP_OPT_COMPRESS_WINDOW_GLOBAL_SLOTS; profiles/r06c_compress_mix_l2_slots*.jsonl)
+    u32 win_dual_min = 4096; // auto mode: window-kernel batches of at least this many fragments run BOTH table forms side by side (compress_win.hip, dual form)
+    // the dual form's side stream and its fork / join events (created on first use, outside any capture)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
+    int side_state = 0;
+    bool side_stream_ready();
+    u32 win_max = 32768;     // auto mode: batches below this many fragments take the window kernel (SNP_OPT_COMPRESS_WINDOW_MAX_BATCH): the lane kernel needs its
+                             // ~31-37 ms whatever the count up to ~20 000 fragments (round 6, against the dual form: 16 383: 32.7 vs 50.2 GB/s; 20 480: 36.1 vs 47.9;
+                             // 24 576: 51.3 dual; 32 768: 50.8-51.7 lanes vs 49.1 dual -- profiles/r06d_compress_by_batch.jsonl, r06e_dual_reserve.txt)
     snp_lane_tuning lane_tune{0, -1, 0, -1, 0, 0};   // SNP_OPT_COMPRESS_LANE_*: launch shape of the lane compressor (0 / -1 = by batch size)
     DevBuf in, out, meta, work, fragtab, scan, small, redo, win_tables;
     int frame_scan = 0;      // header walk of snp_frame_decode_device: 0 spans walked concurrently (frame_scan.hip), 1 one lane, serial (SNP_OPT_FRAME_SCAN)

@@ -34,6 +34,12 @@
 #ifndef SNP_W_PROF
 #define SNP_W_PROF 0
 #endif
+#ifndef SNP_W_PREFILTER
+#define SNP_W_PREFILTER 1   // global-slot form: distinct buckets proven in LDS before the table is touched (0 = always read the table back)
+#endif
+#ifndef SNP_W_PREFILTER_BITS
+#define SNP_W_PREFILTER_BITS 11    // 2 048 slots = 4 KiB per wavefront: 12 bits cost the dual form its LDS room (46.7 against 49.9 GB/s), 10 and 11 measure the same (profiles/r06e_ab_prefilter.jsonl)
+#endif
 #ifndef SNP_W_ASMWALK
 #define SNP_W_ASMWALK 1   // NP == 1: the walk's common case as a hand-written scalar loop
 #endif
@@ -43,6 +49,7 @@ namespace {
 constexpr u32 kCap = SNP_W_CAP;
 constexpr int kPieces = SNP_W_CAP / 16;
 constexpr u32 kNone = 0xffffffffu;
+constexpr u32 kDupMask = (1u << SNP_W_PREFILTER_BITS) - 1u;
 
 // ---- compile-time tables -----------------------------------------------------------------------------------
 struct ProbeTableW {
@@ -338,6 +345,7 @@ __device__ __forceinline__ void compress_win_fragment(const u8* __restrict__ in,
     __shared__ u16 table_lds[GTAB ? 8 : 16384];                         // HashTable.cs:17-18
     __shared__ u16 lut[VARIANT == SNP_HASH_CRC32C ? 1024 : 8];
     __shared__ u64 ring[128];                                           // tokens: position | length << 16 | offset << 32
+    __shared__ u16 dupf[(GTAB && SNP_W_PREFILTER) ? (1u << SNP_W_PREFILTER_BITS) : 8];         // global-slot form: the distinct-bucket prefilter (see the publish step)
     const WinTable<GTAB> table{GTAB ? gtab : table_lds};
 #define lds_fence tab_fence<GTAB>
 
@@ -612,17 +620,32 @@ __device__ __forceinline__ void compress_win_fragment(const u8* __restrict__ in,
                 u32 rb[NP];
                 bool bad = false;
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    pub[k] = (PUB[k] >> lane) & 1ull;
-                    if (pub[k]) table.set(h[k], pp[k]);
+                for (int k = 0; k < NP; ++k) pub[k] = (PUB[k] >> lane) & 1ull;
+                // Global-slot form (round 6): a PREFILTER in LDS first.  The publishing lanes drop their lane number into dupf[bucket mod 4096] and read it
+                // back: when every lane reads its own number the low 12 bits of the buckets are pairwise distinct, hence the buckets are, and the table
+                // stores below need no read-back -- one L2 round trip less in ~4 of 5 rounds (the read-back was 44 % of this form's clock together with the
+                // cut path, profiles/r06_compress_win_phase_clock.jsonl).  A collision in dupf (a real repeated bucket, or two buckets that share their
+                // low bits) takes the exact path through the table as before: the prefilter never decides a cut.
+                bool exact_check = true;
+                if constexpr (GTAB && SNP_W_PREFILTER) {
+                    static_assert(NP == 1, "the global-slot form runs with one position per lane");
+                    if (pub[0]) dupf[h[0] & kDupMask] = static_cast<u16>(lane);
+                    asm volatile("" ::: "memory");                      // (DS operations of a wavefront execute in order)
+                    const u32 rr = pub[0] ? dupf[h[0] & kDupMask] : lane;
+                    exact_check = ballot64(rr != lane) != 0ull;
                 }
-                lds_fence();
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    rb[k] = pub[k] ? table.get(h[k]) : pp[k];
-                    bad = bad || rb[k] != pp[k];
+                for (int k = 0; k < NP; ++k)
+                    if (pub[k]) table.set(h[k], pp[k]);
+                if (exact_check) {
+                    lds_fence();
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        rb[k] = pub[k] ? table.get(h[k]) : pp[k];
+                        bad = bad || rb[k] != pp[k];
+                    }
                 }
-                if (ballot64(bad)) {
+                if (exact_check && ballot64(bad)) {
                     WPROF_ADD(1, 1);
                     // min-position-wins: afterwards every later duplicate reads a smaller position than its own
                     for (;;) {
@@ -689,7 +712,8 @@ __device__ __forceinline__ void compress_win_fragment(const u8* __restrict__ in,
                 WPROF_ADD(2, pushed);
                 cnt += pushed;
                 st = e;
-                lds_fence();
+                if constexpr (GTAB && SNP_W_PREFILTER) asm volatile("" ::: "memory");   // (the table stores are waited for where the next round reads the table; the ring is LDS)
+                else lds_fence();
                 WPROF_T(13);                                            // publish / cut / queue
             } else {
                 // ================================ sparse round ===============================================
@@ -820,6 +844,45 @@ __global__ __launch_bounds__(SNP_WAVE) void k_compress_win_g(const u8* __restric
     }
 }
 
+// DUAL form (round 6): both table forms at once, as two kernels on two streams that draw fragments from ONE ticket counter.  The LDS form is capped
+// by LDS at 4 wavefronts per CU (one per SIMD: 43 % of its cycles issuing, 54 % parked -- profiles/r06_compress_win_pmc.txt), which leaves the SIMDs'
+// issue slots and the L2 mostly idle; a second population of global-slot wavefronts, FEW enough that their 32 KiB slots stay L2-resident (~10 per CU:
+// 2 560 slots = 80 MiB over 8 x 4 MiB of L2 and the Infinity Cache; at 32 per CU the slots thrash L2: TCC hit rate 33 %), fills them.  The ticket
+// balances the two populations whatever their relative speed (a static split loses 3-8 % to the slower side's tail).
+template <int VARIANT>
+__global__ __launch_bounds__(SNP_WAVE) void k_compress_win_q(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                            const u32* __restrict__ in_len, u32 nblocks,
+                                                            u8* __restrict__ out, const u64* __restrict__ out_off,
+                                                            u32* __restrict__ out_len, i32* __restrict__ status,
+                                                            int emit_varint, u32* __restrict__ ticket)
+{
+    for (;;) {
+        u32 b = 0;
+        if (lane_id() == 0) b = atomicAdd(ticket, 1u);
+        b = bcast_first(b);
+        if (b >= nblocks) break;
+        compress_win_fragment<VARIANT, 1, false>(in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, b, nullptr);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the next fragment reuses the LDS arrays)
+    }
+}
+template <int VARIANT>
+__global__ __launch_bounds__(SNP_WAVE) void k_compress_win_gq(const u8* __restrict__ in, const u64* __restrict__ in_off,
+                                                             const u32* __restrict__ in_len, u32 nblocks,
+                                                             u8* __restrict__ out, const u64* __restrict__ out_off,
+                                                             u32* __restrict__ out_len, i32* __restrict__ status,
+                                                             int emit_varint, u16* __restrict__ tables, u32* __restrict__ ticket)
+{
+    u16* const mine = tables + static_cast<size_t>(blockIdx.x) * 16384u;
+    for (;;) {
+        u32 b = 0;
+        if (lane_id() == 0) b = atomicAdd(ticket, 1u);
+        b = bcast_first(b);
+        if (b >= nblocks) break;
+        compress_win_fragment<VARIANT, 1, true>(in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, b, mine);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (the next fragment reuses the slot and the LDS arrays)
+    }
+}
+
 // test hook (include/snappier_hip_debug.h): FindMatchLength by the wave, as the kernel uses it (tests/test_gpu_parity.py runs the reference's KATs through it)
 __global__ __launch_bounds__(SNP_WAVE) void k_debug_match_length(const u8* buf, u32 n, u32 p, u32 cand, u32 known, u32* out)
 {
@@ -833,6 +896,33 @@ extern "C" int snp_debug_match_length(const u8* d_buf, u32 n, u32 p, u32 cand, u
 {
     hipLaunchKernelGGL(k_debug_match_length, dim3(1), dim3(SNP_WAVE), 0, stream, d_buf, n, p, cand, known, d_out);
     return static_cast<int>(hipGetLastError());
+}
+
+// The dual form: `lds_groups` persistent workgroups of the LDS form on `stream`, `slots` of the global-slot form on `side` (forked from and joined back
+// into `stream` through the two events: the pattern stream capture understands), one ticket counter (zeroed here, on `stream`).
+extern "C" hipError_t snp_launch_compress_win_dual(const u8* in, const u64* in_off, const u32* in_len, u32 nblocks, u8* out,
+                                                   const u64* out_off, u32* out_len, i32* status, int variant, int emit_varint,
+                                                   hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join,
+                                                   u16* tables, u32 slots, u32 lds_groups, u32* ticket)
+{
+    if (nblocks == 0) return hipSuccess;
+    hipError_t e = snp_zero_words_async(ticket, 1, stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipEventRecord(fork, stream)) != hipSuccess || (e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return e;
+    const u32 g = nblocks < slots ? nblocks : slots;
+    const u32 l = nblocks < lds_groups ? nblocks : lds_groups;
+    // (leaving the last ~900 fragments to the faster LDS form, so that both populations run dry together, measured worse at five of six batch sizes:
+    //  profiles/r06e_dual_reserve.txt)
+    if (variant == SNP_HASH_CRC32C) {
+        hipLaunchKernelGGL((k_compress_win_gq<SNP_HASH_CRC32C>), dim3(g), dim3(SNP_WAVE), 0, side, in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, tables, ticket);
+        hipLaunchKernelGGL((k_compress_win_q<SNP_HASH_CRC32C>), dim3(l), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, ticket);
+    } else {
+        hipLaunchKernelGGL((k_compress_win_gq<SNP_HASH_MUL>), dim3(g), dim3(SNP_WAVE), 0, side, in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, tables, ticket);
+        hipLaunchKernelGGL((k_compress_win_q<SNP_HASH_MUL>), dim3(l), dim3(SNP_WAVE), 0, stream, in, in_off, in_len, nblocks, out, out_off, out_len, status, emit_varint, ticket);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
+    return hipStreamWaitEvent(stream, join, 0);
 }
 
 #if SNP_W_PROF

@@ -2,7 +2,7 @@
 parametrise over.  No test sets a SNAPPIER_HIP_* variable: the product reads no environment, and every path it contains has an option."""
 from snappier_amd import _native as N
 
-COMPRESS_LAYOUTS = ["win", "win-np2", "wing", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31", "lanes-opts87-slots1", "lanes-opts215-slots1",
+COMPRESS_LAYOUTS = ["win", "win-np2", "wing", "wind", "lanes", "lanes-exact", "lanes-opts7", "lanes-opts31", "lanes-opts87-slots1", "lanes-opts215-slots1",
                     "lanes-opts151-slots2", "lanes-per16", "lanes-slots4"]
 # chains = the default (decode_chains.hip after the small-block policy); wave-only = no pre-pass; serial = decompress.hip's tag-by-tag kernel;
 # small* = every block through the small-block pre-pass first (decompress_small.hip), leftovers to the list kernel (or one workgroup each: -grid)
@@ -11,11 +11,12 @@ DECODE_LAYOUTS = ["chains", "wave-only", "serial", "small", "small-grid", "small
 
 def set_compress_layout(ctx, layout: str):
     """win = one fragment per wavefront, table in LDS (-np2: two window positions per lane); wing = the same with the table in a global slot;
+    wind = both forms side by side (two streams, one ticket counter);
     lanes = one fragment per lane, tables in the HBM workspace (-exact: exact-length stores only; -optsN: SNP_OPT_COMPRESS_LANE_STORES = N;
     -slotsN: N probes per trip; -perN: N fragments per wavefront)."""
     base = layout.split("-")[0]
     ctx.set_option(N.OPT_COMPRESS_LAYOUT, {"auto": N.COMPRESS_AUTO, "win": N.COMPRESS_WINDOW_LDS, "win2": N.COMPRESS_WINDOW_LDS,
-                                           "wing": N.COMPRESS_WINDOW_GLOBAL, "lanes": N.COMPRESS_LANES}[base])
+                                           "wing": N.COMPRESS_WINDOW_GLOBAL, "wind": N.COMPRESS_WINDOW_DUAL, "lanes": N.COMPRESS_LANES}[base])
     ctx.set_option(N.OPT_COMPRESS_WINDOW_POSITIONS, 2 if (base == "win2" or "-np2" in layout) else 1)
     if layout.endswith("-exact"):
         ctx.set_option(N.OPT_COMPRESS_LANE_STORES, 0)

@@ -97,7 +97,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("layout", ["win", "win2", "wing", "lanes"])
+@pytest.mark.parametrize("layout", ["win", "win2", "wing", "wind", "lanes"])
 @pytest.mark.parametrize("variant", [O.HASH_CRC32C, O.HASH_MUL])
 def test_fuzz_compress_bytes_equal_oracle(layout, variant):
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt"), dtype=np.uint8)

@@ -28,13 +28,15 @@ def _oracle_lengths(raw: torch.Tensor, nb: int, variant: int):
     return ref, ref_off.astype(np.int64), ref_len.astype(np.int64)
 
 
-@pytest.mark.parametrize("nb,layout", [(64, None), (4096, None), (24000, None), (24000, "small")])
+@pytest.mark.parametrize("nb,layout", [(64, None), (4096, None), (8192, None), (24000, "lanes"), (24000, "small")])
 def test_batch_calls_replay_from_a_graph_with_the_oracles_bytes(nb, layout):
     html = read_testdata("html")
     variant = O.HASH_CRC32C
     cd = SB.BlockCodec(0, variant)
     cd.ctx.set_option(N.OPT_TABLE_PROBE_TRIES, 1)                             # (24 000 fragments: the lane compressor, a 1.6 GB workspace, no placement search in a test)
-    if layout:                                                                # the pre-pass + list kernels captured too
+    if nb == 24000:                                                           # the lane compressor under capture (layout 0 gives < 32 768 fragments to the dual per-wavefront form:
+        cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_LANES)            #  that is what the 4 096- and 8 192-fragment cases capture, side stream and all)
+    if layout == "small":                                                     # the pre-pass + list kernels captured too
         import layouts
         layouts.set_decode_layout(cd.ctx, layout, small_max=512)
     raw = SD.html_like_blocks(html, 0, nb, "cuda")

@@ -1039,7 +1039,7 @@ def test_frame_decode_takes_chunks_beyond_64_kib_like_the_reference():
 
 def test_two_threads_share_the_devices_table_pool():
     """the lane compressor's hash-table workspace belongs to the device.  Two caller threads, a context each, compress
-    lane-compressor batches (>= 20 480 fragments each) at the same time: the bytes equal the oracle's, and the library allocates ONE workspace (plus its bounded
+    lane-compressor batches (22 528 fragments each, layout pinned) at the same time: the bytes equal the oracle's, and the library allocates ONE workspace (plus its bounded
     search: at most a second workspace's worth of candidates, transiently), not one per context."""
     import gc
     import threading
@@ -1048,6 +1048,8 @@ def test_two_threads_share_the_devices_table_pool():
     html = read_testdata("html")
     raws = [SD.html_like_blocks(html, 1000 * t, nb, "cuda") for t in range(2)]
     cds = [SB.BlockCodec(0, O.HASH_CRC32C) for _ in range(2)]
+    for cd in cds:
+        cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_LANES)          # (layout 0 hands a batch of this size to the per-wavefront kernels: < 32 768 fragments)
     outs = [torch.empty(nb * cds[0].comp_stride, dtype=torch.uint8, device="cuda") for _ in range(2)]
     out_off = torch.arange(nb, dtype=torch.int64, device="cuda") * cds[0].comp_stride
     in_off, in_len = cds[0].uniform_layout(nb)
