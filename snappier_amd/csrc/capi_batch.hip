@@ -3,6 +3,10 @@
 // as pinned through snp_ctx_set_option).  These calls only enqueue kernels on the context's stream and may be captured into a hipGraph.
 #include "capi_internal.h"
 
+#ifndef SNP_W_DUAL_LDS_PER_CU
+#define SNP_W_DUAL_LDS_PER_CU 4u   // dual form: persistent workgroups of the LDS form per CU (LDS holds four 35 KiB tables)
+#endif
+
 // One launch sequence of the decompressor over nblocks blocks (decompress_small.hip, then decompress.hip).
 bool snp_ctx::launch_decompress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
                        const u32* out_cap, u32* out_len, i32* status, const u8* chunk_type)
@@ -143,7 +147,7 @@ bool snp_ctx::launch_compress(const u8* d_in, const u64* in_off, const u32* in_l
             if (nblocks < slots) slots = nblocks;
             if (!ensure(win_tables, snp_compress_win_table_bytes(slots), "hipMalloc(window tables)") || !ensure(small, 256, "hipMalloc(scalars)")) return false;
             return check(snp_launch_compress_win_dual(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant, emit_varint, stream, side_stream,
-                                                      side_ev[0], side_ev[1], static_cast<uint16_t*>(win_tables.p), slots, per_cu * 4u,
+                                                      side_ev[0], side_ev[1], static_cast<uint16_t*>(win_tables.p), slots, per_cu * SNP_W_DUAL_LDS_PER_CU,
                                                       static_cast<u32*>(small.p) + 16), "compress (windows, dual) launch");
         }
         const bool gtab = compress_mode == 4 || (compress_mode == 0 && nblocks >= win_gtab_min);
