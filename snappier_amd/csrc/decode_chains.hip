@@ -25,7 +25,7 @@
 //             does each tag's source lie?  literals and FAR copies (source ends at or below the held batch's first byte: global memory):
 //             their 16-byte pieces are requested now;
 //     finish  the HELD batch's waiting tags (source inside their own batch, pattern copies), in order, whole wave per tag, a byte per
-//             lane -- the new batch's round trip to memory runs underneath;
+//             lane (lanes beyond the tag's length repeat its last byte: no EXEC mask) -- the new batch's round trip to memory runs underneath;
 //     write   the new batch's pieces are waited for (they are back), then the held batch leaves: stage -> global memory, 16 bytes per lane;
 //     stage   NEAR copies of the new batch (source inside the held batch or the history) read their pieces from the stage; the last 64
 //             bytes of what the stage holds move below its first byte (the new batch's history); every piece is stored; the new batch
@@ -162,10 +162,9 @@ __device__ __forceinline__ void chains_front(DecBlk& B, const u32 lane)
             u64 pend = h_pend;
             while (pend) {
                 u32 f, k;
-                // The plain form, hand-laid: 18 instructions per tag (the compiler's structured version of the same loop: 25 -- 3 % of the
-                // kernel, measured).  Pops tags off `pend` until it is empty or the popped tag (f, k < 0) needs the slow form below.  EXEC
-                // is restored before the block ends; the LDS operations of a wavefront execute in order, so a tag reads what the tag
-                // before it wrote.
+                // The plain form, hand-laid: 16 instructions per tag since round 6 (18 with the EXEC mask of round 5; the compiler's structured
+                // version of the same loop: 25).  Pops tags off `pend` until it is empty or the popped tag (f, k < 0) needs the slow form below.
+                // The LDS operations of a wavefront execute in order, so a tag reads what the tag before it wrote.
 #if SNP_DC_FINISH_MIN
                 // No EXEC mask: lanes at or beyond the tag's length repeat the copy of its LAST byte (same source, same destination, same value):
                 // v_min replaces v_cmp + s_and_saveexec + s_mov exec -- 16 instructions per tag, 9 of them scalar.  (k carries len - 1 here.)
