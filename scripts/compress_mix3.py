@@ -16,9 +16,17 @@ with torch.cuda.stream(st_a):
     lanes = SB.BlockCodec(0, S.HASH_CRC32C); lanes.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_LANES)
     lanes.ctx.reserve_compress(nb)
 with torch.cuda.stream(st_b):
-    dual = SB.BlockCodec(0, S.HASH_CRC32C); dual.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_WINDOW_DUAL)
+    dual = SB.BlockCodec(0, S.HASH_CRC32C); dual.ctx.set_option(N.OPT_COMPRESS_LAYOUT, {"dual": N.COMPRESS_WINDOW_DUAL, "win": N.COMPRESS_WINDOW_LDS, "wing": N.COMPRESS_WINDOW_GLOBAL}[os.environ.get("FORM", "dual")])
     if os.environ.get("SLOTS"): dual.ctx.set_option(N.OPT_COMPRESS_WINDOW_GLOBAL_SLOTS, int(os.environ["SLOTS"]))
-raw = SD.html_like_blocks(html, 0, nb, "cuda")
+kind = os.environ.get("DATA", "html")
+if kind == "html":
+    raw = SD.html_like_blocks(html, 0, nb, "cuda")
+elif kind == "low":
+    raw = SD.low_entropy_blocks(0, nb, "cuda")
+else:
+    td = os.path.join(ROOT, "tests", "golden", "testdata")
+    names = ["alice29.txt", "asyoulik.txt", "fireworks.jpeg", "geo.protodata", "html", "html_x_4", "kppkn.gtb", "lcet10.txt", "paper-100k.pdf", "plrabn12.txt", "urls.10K"]
+    raw = SD.corpus_blocks([(html * 4 if n == "html_x_4" else open(os.path.join(td, n), "rb").read()) for n in names], 0, nb, SD.MIXED_SEED, "cuda")
 stride = lanes.comp_stride
 in_off = torch.arange(nb, dtype=torch.int64, device="cuda") * 65536
 in_len = torch.full((nb,), 65536, dtype=torch.int32, device="cuda")
@@ -43,4 +51,4 @@ for share in shares:
         if it: best = min(best, time.perf_counter() - t0)
     ol = torch.cat(lens)
     same = bool(torch.equal(ol, ref_len))
-    print(json.dumps({"blocks": nb, "share_dual": share, "ms": round(best * 1e3, 2), "GBps": round(nb * 65536 / best / 1e9, 2), "same_lengths": same}), flush=True)
+    print(json.dumps({"data": kind, "form": os.environ.get("FORM", "dual"), "blocks": nb, "share_dual": share, "ms": round(best * 1e3, 2), "GBps": round(nb * 65536 / best / 1e9, 2), "same_lengths": same}), flush=True)
