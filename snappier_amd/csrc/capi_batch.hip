@@ -132,15 +132,14 @@ u32 snp_ctx::persistent_waves()                               // one chip-full o
 bool snp_ctx::launch_compress(const u8* d_in, const u64* in_off, const u32* in_len, u32 nblocks, u8* d_out, const u64* out_off,
                      u32* out_len, i32* status, int emit_varint)
 {
-    // Measured on MI355X (profiles/r02p_compress_by_batch.jsonl, r02_window_kernel.jsonl): the window kernel (LDS tables, 1024 fragments in flight)
-    // runs at the same rate at any batch size and beats the single-token wave kernel everywhere; the lane kernel (HBM
-    // tables) needs >= 16 384 fragments in flight before its memory-level parallelism overtakes it.
-    // ... and between the two, from win_gtab_min fragments on, the window kernel keeps its u16 tables in a 256 MiB global-memory workspace that
-    // stays in L2 / Infinity Cache instead of in LDS (compress_win.hip, WinTable): 32 wavefronts per CU instead of 4.
+    // Measured on MI355X (profiles/r06z_compress_by_batch.jsonl): the per-wavefront kernel with its table in LDS (4 fragments in flight per CU) runs at the
+    // same 34-35 GB/s at any batch size; the lane kernel (HBM tables) needs its 31-37 ms whatever the count up to ~20 000 fragments and overtakes
+    // everything else from 32 768 on.  In between the per-wavefront kernel runs in its DUAL form (below); its global-slot form alone (layout 4) keeps
+    // 12 wavefronts per CU, few enough that their 32 KiB slots stay cache resident.
     const bool win = compress_mode == 3 || compress_mode == 4 || compress_mode == 5 || (compress_mode == 0 && nblocks < win_max);
     if (win) {
-        // ... and from win_dual_min fragments on BOTH forms at once, on two streams, drawing fragments from one ticket counter (compress_win.hip, dual form:
-        // 45-47 GB/s against 34.5 / 36.5 for either alone).  A context whose side stream cannot be created (or a first use under capture) keeps the single form.
+        // From win_dual_min fragments on BOTH forms at once, on two streams, drawing fragments from one ticket counter (compress_win.hip, dual form:
+        // 45-51 GB/s from 6 144 fragments up against 34.5 / 42-45 for either alone).  A context whose side stream cannot be created (or a first use under capture) keeps the single form.
         if ((compress_mode == 5 || (compress_mode == 0 && nblocks >= win_dual_min)) && win_np == 1 && (side_state > 0 || (!stream_is_capturing() && side_stream_ready()))) {
             const u32 per_cu = persistent_waves() / 32u;                 // (= CUs)
             u32 slots = win_gslots ? win_gslots : per_cu * 10u;
