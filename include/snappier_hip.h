@@ -161,7 +161,7 @@ typedef enum snp_option {
     SNP_OPT_FRAME_SCAN = 20,                       /* snp_frame_decode_device header walk: 0 (default) spans walked concurrently, 1 one lane, serial */
     SNP_OPT_DECODE_LDS_THROTTLE = 21,              /* bytes of dynamic LDS requested per decode wavefront purely to cap wavefronts per CU (0 = none; measurements) */
     SNP_OPT_COMPRESS_WINDOW_GLOBAL_SLOTS = 22,     /* per-wavefront compressor, table in a global slot: wavefronts (= 32 KiB slots) it runs with; 0 (default) = 12 per CU alone, 10 beside the LDS form */
-    SNP_OPT_COMPRESS_WINDOW_DUAL_MIN_BATCH = 23    /* layout 0: window-kernel batches of at least this many fragments run both table forms side by side (default 4096) */
+    SNP_OPT_COMPRESS_WINDOW_DUAL_MIN_BATCH = 23    /* layout 0: window-kernel batches of at least this many fragments run both table forms side by side (default 1536) */
 } snp_option;
 #define SNP_OPT_CRC_TABLE_FREE SNP_OPT_CRC_KERNEL   /* deprecated name (rounds 1-4); same number, values 0 / 1 mean the same */
 snp_status snp_ctx_set_option(snp_ctx* ctx, int option, int64_t value);
@@ -227,7 +227,7 @@ snp_status snp_frame_decode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* 
 /* Stream capture: snp_compress_batch, snp_decompress_batch, snp_crc32c_batch and snp_frame_encode_device only enqueue kernels, so they may be called while the context's
  * stream is being captured into a hipGraph and replayed later (the graph reads the device arrays as they are at replay time).  A captured call
  * queries, synchronises and allocates nothing; it therefore needs the workspaces to exist already -- make the same call once before
- * the capture (compress keeps a workspace from 4 096 fragments on, and from there on also forks onto a context-owned side stream that the first such call creates; from 32 768 on snp_ctx_reserve_compress builds the workspace too).  A call that would have to allocate during a capture returns
+ * the capture (compress keeps a workspace from 1 536 fragments on, and from there on also forks onto a context-owned side stream that the first such call creates; from 32 768 on snp_ctx_reserve_compress builds the workspace too).  A call that would have to allocate during a capture returns
  * SNP_ERR_DEVICE (snp_ctx_last_error says so) and leaves the capture valid.  The host-pointer entry points synchronise and cannot be captured.
  * LIFETIME: a captured graph holds the addresses of the workspaces it ran on.  From the first captured call on, the context (and the device's
  * table pool) never frees a workspace it has handed out -- a later, larger call allocates a new one next to it -- until snp_ctx_destroy; a graph
@@ -238,7 +238,7 @@ snp_status snp_frame_decode(snp_ctx* ctx, const uint8_t* in, size_t n, uint8_t* 
  * block b reads in[in_off[b] .. +in_len[b]) and writes  varint(in_len[b]) || CompressFragment  at
  * out[out_off[b] ..), which must have room for snp_max_compressed_length(in_len[b]) bytes.
  * out_len[b] = bytes written, status[b] = SNP_OK | SNP_ERR_BAD_ARG (in_len[b] > 65536).
- * Layout by batch size: below 32 768 fragments one fragment per wavefront with the u16 hash table in LDS -- from 4 096 fragments on joined by a second
+ * Layout by batch size: below 32 768 fragments one fragment per wavefront with the u16 hash table in LDS -- from 1 536 fragments on joined by a second
  * population of wavefronts whose tables sit in cache-resident global-memory slots, both drawing fragments from one ticket counter -- (compress_win.hip), from
  * there on one fragment per LANE with the tables in an HBM workspace the device owns (compress_lanes.hip); all emit the reference's bytes.  All arrays are device memory. */
 snp_status snp_compress_batch(snp_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len,

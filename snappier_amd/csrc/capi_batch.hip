@@ -143,7 +143,9 @@ bool snp_ctx::launch_compress(const u8* d_in, const u64* in_off, const u32* in_l
         if ((compress_mode == 5 || (compress_mode == 0 && nblocks >= win_dual_min)) && win_np == 1 && (side_state > 0 || (!stream_is_capturing() && side_stream_ready()))) {
             const u32 per_cu = persistent_waves() / 32u;                 // (= CUs)
             u32 slots = win_gslots ? win_gslots : per_cu * 10u;
+            if (!win_gslots && nblocks / 4u * 3u < slots) slots = nblocks / 4u * 3u;   // small batches: three quarters of the fragments' worth (3 072 fragments: 42.7 GB/s with 1 536-2 304 slots, 35.7 LDS form alone)
             if (nblocks < slots) slots = nblocks;
+            if (slots == 0) slots = 1;
             if (!ensure(win_tables, snp_compress_win_table_bytes(slots), "hipMalloc(window tables)") || !ensure(small, 256, "hipMalloc(scalars)")) return false;
             return check(snp_launch_compress_win_dual(d_in, in_off, in_len, nblocks, d_out, out_off, out_len, status, variant, emit_varint, stream, side_stream,
                                                       side_ev[0], side_ev[1], static_cast<uint16_t*>(win_tables.p), slots, per_cu * SNP_W_DUAL_LDS_PER_CU,

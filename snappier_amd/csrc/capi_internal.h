@@ -141,7 +141,7 @@ struct snp_ctx {
                              // 36.5 vs 34.6 GB/s from 4 096 fragments up, 19.8 vs 35.5 at 1 024 (profiles/r05zz_compress_by_batch.jsonl)
     u32 win_gslots = 0;      // global-slot window kernel: wavefronts (= 32 KiB table slots) it runs with; 0 = by the form: 12 per CU alone (3 072: 38.9-39.5 GB/s against 36.5 at 32 per CU,
                              // whose slots thrash L2), 10 per CU beside the LDS form (SNP_OPT_COMPRESS_WINDOW_GLOBAL_SLOTS; profiles/r06c_compress_mix_l2_slots*.jsonl)
-    u32 win_dual_min = 4096; // auto mode: window-kernel batches of at least this many fragments run BOTH table forms side by side (compress_win.hip, dual form)
+    u32 win_dual_min = 1536; // auto mode: window-kernel batches of at least this many fragments run BOTH table forms side by side (compress_win.hip, dual form)
     // the dual form's side stream and its fork / join events (created on first use, outside any capture)
     hipStream_t side_stream = nullptr;
     hipEvent_t side_ev[2] = {nullptr, nullptr};

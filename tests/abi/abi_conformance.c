@@ -207,7 +207,7 @@ int main(int argc, char** argv)
         EXPECT(get_option(ctx, SNP_OPT_COMPRESS_SLICE, &v) == SNP_OK && v == 262144 && get_option(ctx, SNP_OPT_COMPRESS_WINDOW_GLOBAL_MIN_BATCH, &v) == SNP_OK && v == 4096);
         EXPECT(set_option(ctx, SNP_OPT_COMPRESS_LAYOUT, 5) == SNP_OK && get_option(ctx, SNP_OPT_COMPRESS_LAYOUT, &v) == SNP_OK && v == 5 &&
                set_option(ctx, SNP_OPT_COMPRESS_LAYOUT, 6) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_COMPRESS_LAYOUT, 1) == SNP_ERR_BAD_ARG && set_option(ctx, SNP_OPT_COMPRESS_LAYOUT, 0) == SNP_OK);
-        EXPECT(get_option(ctx, SNP_OPT_COMPRESS_WINDOW_DUAL_MIN_BATCH, &v) == SNP_OK && v == 4096 && get_option(ctx, SNP_OPT_COMPRESS_WINDOW_GLOBAL_SLOTS, &v) == SNP_OK && v == 0 &&
+        EXPECT(get_option(ctx, SNP_OPT_COMPRESS_WINDOW_DUAL_MIN_BATCH, &v) == SNP_OK && v == 1536 && get_option(ctx, SNP_OPT_COMPRESS_WINDOW_GLOBAL_SLOTS, &v) == SNP_OK && v == 0 &&
                get_option(ctx, SNP_OPT_COMPRESS_WINDOW_MAX_BATCH, &v) == SNP_OK && v == 32768 && set_option(ctx, SNP_OPT_COMPRESS_WINDOW_GLOBAL_SLOTS, 70000) == SNP_ERR_BAD_ARG);
         EXPECT(SNP_OPT_CRC_TABLE_FREE == SNP_OPT_CRC_KERNEL && set_option(ctx, SNP_OPT_CRC_TABLE_FREE, 1) == SNP_OK && get_option(ctx, SNP_OPT_CRC_KERNEL, &v) == SNP_OK && v == 1 &&
                set_option(ctx, SNP_OPT_CRC_KERNEL, 0) == SNP_OK);
