@@ -35,4 +35,16 @@ def run(touch):
 for touch in (0, 2 << 20, 64 << 10, 4 << 10):
     ms = run(touch)
     print(json.dumps({"touch_stride": touch, "touch_ms": round(min(a for a, _ in ms), 3), "decode_ms": [round(b, 3) for _, b in ms]}), flush=True)
+# second hypothesis: the compress launch leaves ~290 MB of dirty table sectors in L2 / Infinity Cache; a streaming fill of FLUSH bytes between the launches pushes them out first
+scratch = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
+for flush in (256 << 20, 1 << 30, 2 << 30):
+    ms = []
+    for it in range(5):
+        _o, _oo, out_len, st = cd.compress(raw, in_off, in_len, out=comp, out_off=comp_off)
+        t0, t1, t2 = ev(), ev(), ev()
+        t0.record(); scratch[:flush].zero_(); t1.record()
+        cd.decompress(comp, comp_off, out_len, back, in_off, in_len)
+        t2.record(); torch.cuda.synchronize()
+        if it: ms.append((t0.elapsed_time(t1), t1.elapsed_time(t2)))
+    print(json.dumps({"flush_bytes": flush, "flush_ms": round(min(a for a, _ in ms), 3), "decode_ms": [round(b, 3) for _, b in ms]}), flush=True)
 assert torch.equal(back, raw)
