@@ -541,7 +541,7 @@ def main():
         alone = {"decompress_ms_alone": round(float(np.mean(a_ms[1:])), 3), "launches_ms": [round(x, 3) for x in a_ms],
                  "how": "six decode-only launches back to back after the timed steps (HIP events on the launch stream; the first follows idle time and is left out of the mean)",
                  "clocks_mhz": clk or "not readable on this host (no hwmon freq1_input for the device)",
-                 "clocks_how": "shader clock (sysfs hwmon freq1_input) and the current memory / fabric clock levels (pp_dpm_mclk, pp_dpm_fclk) of this GPU, read from the host while the launch runs (60 % into a compress launch; half way into the decode launch "
+                 "clocks_how": "shader clock (sysfs hwmon freq1_input) and the current memory / fabric clock levels (pp_dpm_mclk, pp_dpm_fclk) of this GPU, read from the host (NOTE: targets, not the effective clock -- cycles / duration from PMC shows 2.13-2.15 GHz for the decode launch that follows a compress launch against 2.37-2.38 steady: profiles/r06p_decode_effective_clock.txt, DESIGN 7.1) -- while the launch runs (60 % into a compress launch; half way into the decode launch "
                              "that follows a compress launch; during the fourth of four back-to-back decode launches) and right after it finished"}
 
     # ---- what the placement search is worth: the same kernels on a PLAIN one-allocation workspace (second context, SNP_OPT_TABLE_PROBE_TRIES = 1) ----
