@@ -1,4 +1,4 @@
-"""Compress throughput of both layouts vs batch size (sets the auto-selection threshold in capi.hip)."""
+"""Compress throughput of both layouts vs batch size (sets the auto-selection threshold in capi_batch.hip)."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

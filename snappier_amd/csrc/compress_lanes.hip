@@ -638,7 +638,7 @@ emit_remainder:
 // ---- workspace placement probe ---------------------------------------------------------------------------------
 // The kernel is bound by the rate at which HBM serves random 4-byte exchanges spread over the whole table workspace, and that rate
 // depends on WHERE the driver placed the memory (regions of three kinds; the traffic wants to be spread over them: piece_search.h,
-// DESIGN.md 4.3).  This probe is the measuring instrument of the search that picks the workspace's pieces (capi.hip, ensure_tables):
+// DESIGN.md 4.3).  This probe is the measuring instrument of the search that picks the workspace's pieces (capi_pool.hip, ensure_tables):
 // the table traffic of the compressor and nothing else -- every lane walks a chain of dependent exchanges through its own 64 KiB table --
 // on a SET of candidate pieces.  A set smaller than the workspace is probed folded (several lanes per table), so that one or two
 // pieces see the whole grid's concurrency: one 0.6 GiB piece alone 3.4-3.6 ms per 512 probes when it straddles kinds, 3.9 when it does

@@ -9,7 +9,7 @@
 // -- untouched, marked kRedoStatus and appended to a list; decompress.hip decodes exactly those and owns every error code.
 //   k_decompress_small      one block per LANE, global memory: the best layout for blocks of <= ~48 bytes (64 blocks per wavefront)
 //   k_decompress_teams<T>   one block per TEAM of T = 4 / 8 / 16 lanes, compressed and decoded bytes in LDS, coalesced I/O
-//   k_sample_caps           what a batch that skipped the pre-pass looked like (the host's policy, capi.hip launch_decompress)
+//   k_sample_caps           what a batch that skipped the pre-pass looked like (the host's policy, capi_batch.hip launch_decompress)
 // Which one runs, and with how much LDS per wavefront, is decided per batch from the previous batch's read-back (HISTORY.md §4.1b).
 //
 // k_decompress_small: every lane decodes its own block, and the loop is shaped so that one tag costs ONE dependent memory round trip:
@@ -41,7 +41,7 @@ __device__ __forceinline__ void append_redo(bool mine, u32 b, u32* __restrict__ 
 }
 
 // Every 64th wavefront of a pre-pass kernel also reports the capacities it saw (ctl[66] += their sum, ctl[67] += how many): the
-// host reads them back with the sub-list lengths and sizes the NEXT batch's pre-pass by the mean block size (capi.hip).
+// host reads them back with the sub-list lengths and sizes the NEXT batch's pre-pass by the mean block size (capi_batch.hip).
 __device__ __forceinline__ void sample_sizes(bool live, u32 cap, u32* __restrict__ ctl)
 {
     if (!ctl || (blockIdx.x & 63u) != 0) return;

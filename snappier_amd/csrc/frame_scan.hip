@@ -15,7 +15,7 @@
 //   C  k_span_emit        one wavefront per span: walk the span again from its true entry and write the chunk table rows at
 //                         their final indices; entries past the last chunk become empty chunks (the decode and CRC launches
 //                         run over max_chunks rows without a host round trip).
-// The rules of one hop (frame_hop) are those of the host walk in capi.hip (scan_chunks); the table is what it produces.
+// The rules of one hop (frame_hop) are those of the host walk in capi_frame.hip (scan_chunks); the table is what it produces.
 #include "snp_device.h"
 
 namespace {
@@ -36,7 +36,7 @@ struct Hop {
     u64 next;       // position of the next header
 };
 
-// One header at ip (< n or == n).  Same rules, in the same order, as scan_chunks (capi.hip) / the reference reader.
+// One header at ip (< n or == n).  Same rules, in the same order, as scan_chunks (capi_frame.hip) / the reference reader.
 __device__ __forceinline__ Hop frame_hop(const u8* __restrict__ in, u64 n, u64 ip)
 {
     Hop h{};
@@ -72,7 +72,7 @@ __device__ __forceinline__ Hop frame_hop(const u8* __restrict__ in, u64 n, u64 i
             }
             if (bad || !done || result > 0x7fffffffu) { h.kind = HOP_ERR; h.err = SNP_ERR_BAD_LENGTH; return h; }
             dec = result;
-            // no tag expands more than 3 bytes -> 64: such a chunk can only end "Incomplete Snappy block." (capi.hip scan_chunks)
+            // no tag expands more than 3 bytes -> 64: such a chunk can only end "Incomplete Snappy block." (capi_frame.hip scan_chunks)
             if (static_cast<u64>(dec) > (static_cast<u64>(size - 4 - (shift / 7)) / 3 + 1) * 64) { h.kind = HOP_ERR; h.err = SNP_ERR_INCOMPLETE; return h; }
         }
         h.kind = HOP_DATA;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_frame_emit(const u8* __restrict__ raw, 
 // ---- device-side chunk-header walk (SnappyStreamDecompressor.ReadChunkHeader / Decompress  :53-199,215-289) -----
 // A framed stream carries no index: every header gives the position of the next one, so the walk is a serial chain of
 // ~64 KiB hops (one 16-byte load per chunk: type, 24-bit size, masked CRC and the first bytes of the block preamble).
-// One lane walks; the table it writes is exactly what the host walk in capi.hip produces.  Entries past the last data
+// One lane walks; the table it writes is exactly what the host walk in capi_frame.hip produces.  Entries past the last data
 // chunk are filled as empty uncompressed chunks so that the decode and CRC launches can run over max_chunks without
 // knowing the count on the host.
 constexpr u32 kEmptyMaskedCrc = 0xa282ead8u;      // crc32c_mask(crc32c of no bytes = 0)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SNP_WAVE) void k_frame_scan(const u8* __restrict__ 
                     }
                     if (bad || !done || result > 0x7fffffffu) { tail = SNP_ERR_BAD_LENGTH; break; }
                     dec = result;
-                    // no tag expands more than 3 bytes -> 64: such a chunk can only end "Incomplete Snappy block." (capi.hip scan_chunks)
+                    // no tag expands more than 3 bytes -> 64: such a chunk can only end "Incomplete Snappy block." (capi_frame.hip scan_chunks)
                     if (static_cast<u64>(dec) > (static_cast<u64>(size - 4 - (shift / 7)) / 3 + 1) * 64) { tail = SNP_ERR_INCOMPLETE; break; }
                 }
                 if (nc == max_chunks) { tail = SNP_ERR_OUTPUT_TOO_SMALL; break; }   // chunk table full

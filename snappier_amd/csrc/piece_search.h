@@ -1,4 +1,4 @@
-// piece_search.h -- which separately allocated pieces the lane compressor's hash-table workspace is made of.  Plain C++ (no HIP): capi.hip
+// piece_search.h -- which separately allocated pieces the lane compressor's hash-table workspace is made of.  Plain C++ (no HIP): capi_pool.hip
 // supplies the allocator and the probe; tests/test_piece_search_model.py drives the same code with a model of device memory on the CPU.
 #pragma once
 #include <stdint.h>
@@ -36,7 +36,7 @@ struct PieceSearch {
     size_t max_cand = 0;                         // candidates the search may hold at once
     double piece_gib = 0;                        // (for the debug lines)
     bool dbg = false;
-    // The two things the search does to the device, supplied by the caller (capi.hip: hipMalloc / snp_probe_tables; the CPU test: a model):
+    // The two things the search does to the device, supplied by the caller (capi_pool.hip: hipMalloc / snp_probe_tables; the CPU test: a model):
     std::function<bool()> alloc_one;                                 // one more candidate; false = out of memory
     std::function<float(const std::vector<u32>&)> probe_set;         // ms of 512 table-walk probes per fragment on these candidates (folded when fewer than n)
     size_t ncand = 0;

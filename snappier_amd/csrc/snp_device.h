@@ -15,7 +15,7 @@ typedef int32_t i32;
 #define SNP_WAVE 64
 
 // The SNAPPIER_HIP_* environment variables are test and A/B knobs (kernel variants, layouts, thresholds): the product library reads NONE of them.
-// Only libraries built with -DSNAPPIER_HIP_DEBUG_ENV do (scripts/build_variant.sh, LAB=1: snappier_amd/variants/, loaded by the tests that vary a knob).
+// Only variant libraries built with -DSNAPPIER_HIP_DEBUG_ENV do (scripts/build_variant.sh, LAB=1: snappier_amd/variants/, loaded by A/B scripts on request; no test loads one).
 #ifdef SNAPPIER_HIP_DEBUG_ENV
 #include <stdlib.h>
 #define SNP_GETENV(name) getenv(name)
@@ -25,7 +25,7 @@ typedef int32_t i32;
 
 // The lane compressor's hash-table workspace (compress_lanes.hip): up to 16 separately allocated PIECES of `piece_frags` fragments' tables each
 // (a multiple of 64, so a workgroup's tables never straddle two pieces); fragment f's table is table f % piece_frags of piece f / piece_frags.
-// A workspace that is one allocation is one piece with piece_frags = 0xffffffc0.  Why pieces: capi.hip, ensure_tables.
+// A workspace that is one allocation is one piece with piece_frags = 0xffffffc0.  Why pieces: capi_pool.hip, build_tables.
 #define SNP_TABLE_PIECES_MAX 16
 struct snp_table_pieces {
     uint32_t* p[SNP_TABLE_PIECES_MAX];

@@ -568,7 +568,7 @@ extern "C" size_t snp_tag_index_workspace_bytes(u32 n, u32 hb)
 extern "C" size_t snp_tag_index_fallback_offset(u32 n, u32 hb) { return 2 * ws_entries(snp_tag_index_entries(n, hb)) + 8; }   // (ctl[2])
 
 // The workspace holds snp_tag_index_workspace_bytes(n, hb) bytes; its first snp_tag_index_entries words are the entry table when the fallback flag is 0
-// (the debug dump in capi.hip reads those).  Three steps, so that a caller who uploads the stream in slices can index what has arrived:
+// (the debug dump in capi_host.hip reads those).  Three steps, so that a caller who uploads the stream in slices can index what has arrived:
 //   snp_launch_tag_index_begin   zeroes the control words;
 //   snp_launch_tag_index_chunks  k_tag_cand for chunks [first, first + count), IN ORDER (the tickets number the chunks across launches); chunk k
 //                                needs stream bytes [hb + k * 16 KiB, hb + (k + 1) * 16 KiB + 8) on the device (snp_tag_index_chunks_ready);

@@ -357,7 +357,7 @@ def test_crc32c_table_free_kernel_equals_the_table_kernel_and_the_oracle():
 
 def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
     """A lane-compressor batch whose hash-table workspace is >= 1 GiB runs on up to 16 separately allocated pieces picked by the placement
-    search (capi.hip, TablePool / PieceSearch) -- the DEVICE's workspace, which every context borrows; with SNP_OPT_TABLE_PROBE_TRIES = 1 on a
+    search (capi_pool.hip, TablePool / PieceSearch) -- the DEVICE's workspace, which every context borrows; with SNP_OPT_TABLE_PROBE_TRIES = 1 on a
     plain allocation of the context's own; when the byte cap leaves no room for spare candidates, on unsearched pieces.  All of them must
     return the oracle's bytes: every block compared by length and CRC across the forms, the blocks either side of every piece boundary (and
     the ragged tail) byte for byte against the oracle; a second, larger batch makes the pool grow (pieces freed, bounded search repeated)."""
@@ -413,7 +413,7 @@ def test_hash_table_workspace_in_pieces_gives_the_same_bytes():
         if nb == sizes[0]:
             assert searched.ctx.counter(3) == at_reserve, "the compress call searched again after snp_ctx_reserve_compress"
         assert 16 < searched.ctx.counter(3) <= 32 and searched.ctx.counter(2) > 0, "the search did not run (or went beyond its default budget)"
-        piece = ((nb + nb // 16 + 15) // 16 + 63) // 64 * 64            # capacity = the batch + 1/16 of slack (capi.hip, build_tables)
+        piece = ((nb + nb // 16 + 15) // 16 + 63) // 64 * 64            # capacity = the batch + 1/16 of slack (capi_pool.hip, build_tables)
         check = sorted({b for k in range(1, 16) for b in (k * piece - 1, k * piece) if b < nb} | {0, nb // 2, nb - 2, nb - 1})
         idx = torch.tensor(check, device="cuda")
         sub = torch.cat([raw[int(off[b]): int(off[b]) + int(lens[b])] for b in check]).cpu().numpy()
@@ -523,7 +523,7 @@ def _compare_batch(cd, data, off, lens, variant, what):
 
 
 def test_batches_beyond_one_launch_slice_equal_oracle():
-    """A lane-compressor batch of more than 262 144 fragments runs as several launches over one hash-table workspace (capi.hip, slice_fragments), and
+    """A lane-compressor batch of more than 262 144 fragments runs as several launches over one hash-table workspace (capi_batch.hip, slice_fragments), and
     the decoder's small-block pre-pass sees more blocks than any other test gives it: 600 000 blocks of 0..300 bytes in ONE call, every block equal to
     the oracle and back.  Then the same seam at full fragment size: SNP_OPT_COMPRESS_SLICE = 4096 cuts 9 000 mixed fragments (up to 64 KiB) into three launches."""
     text = np.frombuffer(read_testdata("html") + read_testdata("alice29.txt") + read_testdata("geo.protodata"), dtype=np.uint8)

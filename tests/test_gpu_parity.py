@@ -477,7 +477,7 @@ def test_streams_built_against_the_sub_chain_decoder(decode):
 
 def test_one_context_through_batches_of_changing_block_sizes():
     """The decode policy of a context follows its previous batch (small-block pre-pass layout by mean block size; no pre-pass after
-    a batch of large blocks; capi.hip launch_decompress).  One context, batches of 40 / 200 / 65536 / 300 / 65536 / 40 / 1000-byte
+    a batch of large blocks; capi_batch.hip launch_decompress).  One context, batches of 40 / 200 / 65536 / 300 / 65536 / 40 / 1000-byte
     blocks, each decoded twice (the second call sees the first one's read-back): every block round-trips, a sample equals the
     oracle, whatever the context remembered."""
     cd = SB.BlockCodec(0, O.HASH_CRC32C)

@@ -1,4 +1,4 @@
-"""The lane compressor's workspace search (snappier_amd/csrc/piece_search.h -- the very code capi.hip runs at the first large compress
+"""The lane compressor's workspace search (snappier_amd/csrc/piece_search.h -- the very code capi_pool.hip runs at the first large compress
 call) against a model of device memory on the CPU: tests/abi/piece_search_model.cpp gives every candidate piece a share of each of three
 kinds of memory and prices a probe as the microbenchmark measured it.  What must hold: the search finds a set spread
 over three kinds when they turn up early, over two otherwise, keeps allocating while only one kind has been seen, stops at its
