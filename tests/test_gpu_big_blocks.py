@@ -206,14 +206,15 @@ def test_work_follows_torch_streams():
     assert same and int((status != 0).sum()) == 0 and int((dst != 0).sum()) == 0
 
 
-def test_one_context_alternating_between_two_streams_keeps_its_scratch_ordered():
-    """The lane compressor's hash tables live in context-owned HBM scratch.  A context that is rebound from one torch
-    stream to another (double buffering) must not let the second launch's memset + kernel run on the tables while the
-    first is still using them: snp_ctx_set_stream orders the new stream behind the old one.  Both results must be the
-    oracle's bytes."""
+@pytest.mark.parametrize("layout", ["lanes", "dual"])
+def test_one_context_alternating_between_two_streams_keeps_its_scratch_ordered(layout):
+    """The lane compressor's hash tables -- and the dual per-wavefront form's table slots and ticket counter -- live in scratch the context
+    (or its device) owns.  A context that is rebound from one torch stream to another (double buffering) must not let the second launch's
+    memset + kernels run on them while the first is still using them: snp_ctx_set_stream orders the new stream behind the old one (the dual
+    form's side stream is forked from and joined into whichever stream the call runs on).  All results must be the oracle's bytes."""
     from snappier_amd import batch as SB, datagen as SD
     cd = SB.BlockCodec(0, O.HASH_CRC32C)
-    cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_LANES)
+    cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_LANES if layout == "lanes" else N.COMPRESS_WINDOW_DUAL)
     html = read_testdata("html")
     nb = 4096
     raws = [SD.html_like_blocks(html, 100 + 7 * k, nb, "cuda") for k in range(4)]
@@ -344,3 +345,41 @@ def test_framed_stream_beyond_4_gib_matches_oracle():
     # a flipped payload byte beyond the 4 GiB mark is caught by that chunk's CRC (or its decoder) and nowhere else
     framed[w.value - 1000] ^= 0x40
     assert L.snp_frame_decode(ctx.handle, framed.ctypes.data, w.value, back.ctypes.data, n, C.byref(wb)) != 0
+
+
+def test_two_threads_run_the_dual_form_at_once():
+    """Two caller threads, a context each (own stream, own side stream, own table slots and ticket), compress batches of 3 000 fragments in the
+    dual per-wavefront form at the same time, three times over: every sampled block equals the oracle's bytes, every status is OK."""
+    import threading
+    from snappier_amd import batch as SB, datagen as SD
+    html = read_testdata("html")
+    nb = 3000
+    raws = [SD.html_like_blocks(html, 31 * t, nb, "cuda") for t in range(2)]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def work(t):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                cd = SB.BlockCodec(0, O.HASH_CRC32C)
+                cd.ctx.set_option(N.OPT_COMPRESS_LAYOUT, N.COMPRESS_WINDOW_DUAL)
+                in_off, in_len = cd.uniform_layout(nb)
+                for _ in range(3):
+                    out, out_off, out_len, status = cd.compress(raws[t], in_off, in_len)
+                st.synchronize()
+                results[t] = (out.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy(), cd.comp_stride)
+                cd.ctx.close()
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors
+    for t in range(2):
+        out, lens, status, stride = results[t]
+        assert (status == 0).all()
+        h_raw = raws[t].cpu().numpy()
+        for b in range(0, nb, 97):
+            assert out[b * stride: b * stride + int(lens[b])].tobytes() == O.compress(h_raw[b * 65536:(b + 1) * 65536].tobytes(), O.HASH_CRC32C), (t, b)
