@@ -814,7 +814,7 @@ def main():
                                      "the device's hash-table workspace built by snp_ctx_reserve_compress before the buffers are allocated (a service's start-up: untimed, like the setup pass; its cost is workspace_search), " +
                                      ("with the THOROUGH placement search asked for explicitly (--thorough-search: SNP_OPT_TABLE_PROBE_TRIES = 24; what the default bounded search gives is value_default_search)" if thorough else
                                       "LIBRARY DEFAULT options: the bounded placement search (<= two workspaces' worth of candidates, <= half of free memory)")),
-                       "value_range_seen": "placement of the 10.7 GB of hash tables decides +-8 % of the compressor's rate (random read-modify-writes: where hipMalloc landed, DESIGN 4.3/7.3): round 5 boxes 86.9-101.6 GB/s (plain 81.0-90.1, default search 91.9-101.2, thorough 96.0-101.6); round 6, default search on three boxes: 94.6 / 96.3 / 101.0 (plain 80.3-84.2, thorough 100.8)",
+                       "value_range_seen": "placement of the 10.7 GB of hash tables decides +-8 % of the compressor's rate (random read-modify-writes: where hipMalloc landed, DESIGN 4.3/7.3): round 5 boxes 86.9-101.6 GB/s (plain 81.0-90.1, default search 91.9-101.2, thorough 96.0-101.6); round 6, default search on four boxes: 94.6 / 96.3 / 96.6 / 101.0 (plain 80.3-84.2, thorough 100.8)",
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "compression_ratio": round(c_bytes / u_bytes, 4), "parallelism": f"block-sharded x{world}, no data-path collective"},
             "compress_GBps": round(u_bytes * world / (ms_c * 1e-3) / 1e9, 2) if world == 1 else None,
